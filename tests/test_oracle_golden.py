@@ -1,0 +1,177 @@
+"""Pins the CPU oracle (oracle/cm_oracle.c) against every golden vector generated from the
+reference (oracle/gen_golden.py): integer state bit-exact, obs / reward exact, in RNG-tape mode."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ENV_FIXTURES = sorted(glob.glob(os.path.join(GOLDEN, "env_*.npz")))
+
+
+def replay(path, make_env, check_every=1):
+    """Shared replay loop: make_env(cfg) -> object with the OracleEnv interface."""
+    z = np.load(path)
+    cfgj = json.loads(str(z["cfg"]))
+    T, B = z["actions"].shape[:2]
+    cfg = O.cfg_from_json(cfgj, B, rng_mode=O.RNG_TAPE)
+    env = make_env(cfg)
+    pp = cfgj["scenario"] == "pp"
+
+    def tape_at(prefix, t=None):
+        def g(k):
+            k = prefix + k
+            if k not in z.files:
+                return None
+            return z[k] if t is None else z[k][t]
+        return dict(prey=g("prey_tape"), spawn=g("spawn_tape"), iid_u=g("iid_u"), ge_u=g("ge_u"))
+
+    def check_state(t, where):
+        np.testing.assert_array_equal(env.agent_pos, z["agent_pos"][t], err_msg=f"agent_pos {where}")
+        np.testing.assert_array_equal(env.step_count, z["step_count"][t], err_msg=f"step_count {where}")
+        if pp:
+            alive = z["prey_alive"][t].astype(bool)
+            np.testing.assert_array_equal(env.prey_alive.astype(bool), alive, err_msg=f"alive {where}")
+            # a dead prey's stale position is not observable; compare live ones
+            np.testing.assert_array_equal(env.prey_pos[alive], z["prey_pos"][t][alive], err_msg=f"prey_pos {where}")
+        else:
+            np.testing.assert_array_equal(env.visited_dense(), z["visited"][t], err_msg=f"visited {where}")
+            np.testing.assert_array_equal(env.total_capture, z["total_capture"][t], err_msg=f"total_capture {where}")
+        np.testing.assert_array_equal(env.obs.reshape(B, -1), z["obs"][t], err_msg=f"obs {where}")
+        np.testing.assert_array_equal(env.dist_adj, z["dist_adj"][t], err_msg=f"dist_adj {where}")
+        np.testing.assert_array_equal(env.channels, z["channels"][t], err_msg=f"channels {where}")
+
+    env.reset(**tape_at("init_"))
+    check_state(0, "after reset")
+    for t in range(T):
+        env.step(z["actions"][t], **tape_at("", t))
+        where = f"step {t}"
+        np.testing.assert_array_equal(env.done, z["done"][t], err_msg=f"done {where}")
+        np.testing.assert_array_equal(env.reward, z["reward"][t], err_msg=f"reward {where}")
+        np.testing.assert_array_equal(env.details[:, :5], z["details"][t][:, :5], err_msg=f"details {where}")
+        np.testing.assert_array_equal(env.success, z["success"][t + 1], err_msg=f"success {where}")
+        if pp:
+            np.testing.assert_array_equal(env.prey_alive_info, z["prey_alive_info"][t], err_msg=f"info {where}")
+        if t % check_every == 0 or t == T - 1:
+            check_state(t + 1, where)
+    return z, env
+
+
+@pytest.mark.parametrize("path", ENV_FIXTURES, ids=[os.path.basename(p)[4:-4] for p in ENV_FIXTURES])
+def test_env_oracle_matches_reference(path):
+    replay(path, O.OracleEnv)
+
+
+def test_fixture_set_is_complete():
+    names = {os.path.basename(p) for p in ENV_FIXTURES}
+    for need in ("env_pp_map10_cap2.npz", "env_pp_map30_cap4.npz", "env_co_map20.npz", "env_co_map30_iid.npz",
+                 "env_co_map20_ge.npz"):
+        assert need in names
+
+
+def test_co_constants():
+    z = np.load(os.path.join(GOLDEN, "env_co_map20.npz"))
+    cfg = O.cfg_from_json(str(z["cfg"]), 1)
+    env = O.OracleEnv(cfg)
+    assert env.n_empty_cells == int(z["n_empty_cells"]) == 320
+    # bound_return (coverage.py:214-219) = cap*n_empty/N - |step|*n_empty/N + final
+    n = cfg.n_agents
+    assert cfg.capture_reward * env.n_empty_cells / n - abs(cfg.step_cost) * env.n_empty_cells / n + 100 == float(
+        z["bound_return"])
+
+
+def test_ge_transition_direct():
+    z = np.load(os.path.join(GOLDEN, "ge_direct.npz"))
+    s = np.ones(z["states"].shape[1:], np.uint8)
+    for h in range(z["states"].shape[0]):
+        s = O.ge_transition(s, z["u"][h, 0], z["u"][h, 1], float(z["pgb"]), float(z["pbg"]))
+        np.testing.assert_array_equal(s, z["states"][h], err_msg=f"hop {h}")
+    assert z["states"].min() == 0     # some links did go bad
+
+
+def test_adjacency_ties():
+    """Integer rule dx^2+dy^2 <= 2*Rcom^2 == f32 cdist <= Rcom_th incl. exact ties."""
+    z = np.load(os.path.join(GOLDEN, "adj_ties.npz"))
+    for n in (4, 24, 26, 54, 72):
+        cfg = O.make_cfg("pp", 1, n, 40, 1, n_preys=0, rcom=9, rng_mode=O.RNG_TAPE)
+        env = O.OracleEnv(cfg)
+        env.agent_pos[0] = z[f"pos_{n}"]
+        env.step_count[:] = 0
+        # a no-op step re-emits the adjacency (no preys -> done, so use max_steps large and M=0 => done)
+        pos = z[f"pos_{n}"].astype(np.int64)
+        d2 = ((pos[:, None, :] - pos[None, :, :]) ** 2).sum(-1)
+        np.testing.assert_array_equal((d2 <= 162).astype(np.float32), z[f"adj_{n}"])
+        assert ((d2 == 162).sum()) >= 2
+
+
+def test_philox_known_answers():
+    """Random123 known-answer vectors for philox4x32-10."""
+    kat = [
+        ((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+        ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+        ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+         (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)),
+    ]
+    for ctr, key, want in kat:
+        assert tuple(int(x) for x in O.philox(ctr, key)) == want
+
+
+POLICY_FIXTURES = [("policy_pp_map10", 4), ("policy_co_map20", 24), ("policy_pp_map30", 72),
+                   ("policy_co_map30_iid", 54)]
+
+
+@pytest.mark.parametrize("name,n_agents", POLICY_FIXTURES)
+def test_policy_critic_forward(name, n_agents):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    pol = {k[4:]: z[k] for k in z.files if k.startswith("pol.")}
+    crit = {k[5:]: z[k] for k in z.files if k.startswith("crit.")}
+    S = z["obs"].shape[0]
+    ones = np.ones((S, n_agents, 5), np.float32)
+    probs, attn, emb = O.policy_forward(pol, z["obs"], ones, z["adj"], z["channels"], n_agents, want_emb=True)
+    tol = dict(rtol=1e-5, atol=1e-5)      # north_star float tolerance
+    np.testing.assert_allclose(probs, z["probs"], **tol)
+    np.testing.assert_allclose(attn, z["attn"], **tol)
+    for l in range(emb.shape[1]):
+        np.testing.assert_allclose(emb[:, l], z[f"emb{l}"], **tol)
+    probs_m, _ = O.policy_forward(pol, z["obs"], z["avail_masked"], z["adj"], z["channels"], n_agents)
+    np.testing.assert_allclose(probs_m, z["probs_masked"], **tol)
+    # entropy = mean over agents, log-lik = sum over agents (comm_categorical_mlp_policy.py:121-137)
+    ent = -(probs * np.log(probs)).sum(-1).mean(-1)
+    np.testing.assert_allclose(ent, z["entropy"], **tol)
+    a = z["actions"]
+    ll = np.log(np.take_along_axis(probs, a[..., None], -1)[..., 0]).sum(-1)
+    np.testing.assert_allclose(ll, z["loglik"], rtol=1e-5, atol=1e-5 * n_agents)
+    v = O.critic_forward(crit, z["obs"], z["adj"], z["channels"], n_agents)
+    np.testing.assert_allclose(v, z["values"], rtol=1e-5, atol=1e-5 * n_agents)
+    closs = O.critic_loss(v, z["returns"], log_std=float(crit["baseline_aggregator._init_std"][0]))
+    np.testing.assert_allclose(closs, z["critic_loss"], rtol=1e-5)
+
+
+def test_ppo_math():
+    z = np.load(os.path.join(GOLDEN, "ppo_math.npz"))
+    lens = z["lens"]
+    g, lam = float(z["gamma"]), float(z["lam"])
+    for p, n in enumerate(lens):
+        r = O.discount_cumsum(z["rewards_pad"][p, :n], g)
+        np.testing.assert_array_equal(r, z["returns"][p, :n])          # f64 recurrence -> exact f32
+        assert (z["returns"][p, n:] == 0).all()
+    adv = O.gae(z["rewards_pad"].astype(np.float32), z["baselines"], g, lam)
+    np.testing.assert_allclose(adv, z["adv"], rtol=1e-5, atol=1e-5)
+    advn = O.normalize_advantages(z["adv"], lens)
+    np.testing.assert_allclose(advn, z["adv_norm"], rtol=1e-5, atol=1e-5)
+    loss = O.ppo_loss(z["adv_norm"], z["new_ll"], z["old_ll"], z["ent"], lens)
+    np.testing.assert_allclose(loss, z["loss"], rtol=1e-5)
+
+
+def test_adam_matches_reference_optimizer():
+    z = np.load(os.path.join(GOLDEN, "adam.npz"))
+    p = z["params"][0]
+    m = np.zeros_like(p)
+    v = np.zeros_like(p)
+    for s in range(z["grads"].shape[0]):
+        p, m, v = O.adam_step(p, z["grads"][s], m, v, s + 1)
+        np.testing.assert_allclose(p, z["params"][s + 1], rtol=1e-6, atol=1e-7)
