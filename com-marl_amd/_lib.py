@@ -1,0 +1,128 @@
+"""ctypes binding of libcommarl_hip.so (the C ABI declared in include/commarl.h).
+
+There is no fallback: if the HIP library is missing or does not load, importing the
+binding raises.  Nothing in this package routes through oracle/ or a CPU path.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcommarl_hip.so")
+
+CM_PP, CM_CO = 0, 1
+CHANNELS = {"FC": 0, "FL": 1, "IID": 2, "GE": 3}
+RNG_PHILOX, RNG_TAPE = 0, 1
+
+
+class EnvCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "scenario", "n_envs", "n_agents", "n_preys", "grid", "rsen", "load", "max_steps", "max_path_length",
+        "n_hops", "rcom", "channel", "obst_hard", "add_clock", "rng_mode", "env_id_offset")] + [
+        ("ploss", C.c_float), ("pgb", C.c_float), ("pbg", C.c_float), ("_pad", C.c_float)] + [
+        (n, C.c_double) for n in ("capture_reward", "step_cost", "move_cost", "penalty", "lazy_penalty",
+                                  "revisit_penalty", "final_reward")] + [("seed", C.c_uint64)]
+
+
+class RngTape(C.Structure):
+    _fields_ = [("prey", C.c_void_p), ("spawn", C.c_void_p), ("spawn_cap", C.c_int32), ("_pad", C.c_int32),
+                ("iid_u", C.c_void_p), ("ge_u", C.c_void_p)]
+
+
+class StepOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("obs", "reward", "reward_f64", "done", "details", "dist_adj", "channels",
+                                          "prey_alive", "success")]
+
+
+class EnvState(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("agent_pos", "prey_pos", "prey_alive", "visited", "step_count",
+                                          "total_capture", "success", "ge_state", "rng_step")]
+
+
+class PolicyWeights(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("d", "n_agents", "n_hops", "enc_hidden", "emb", "h1", "h2", "h3", "n_act",
+                                         "_pad")] + [
+        (n, C.c_void_p) for n in ("enc_w1t", "enc_b1", "enc_w2t", "enc_b2", "attn_wt", "gcn_w", "gcn_b", "hd_w1t",
+                                  "hd_b1", "hd_w2t", "hd_b2", "hd_w3t", "hd_b3", "hd_w4t", "hd_b4")]
+
+
+class CriticWeights(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("d", "n_agents", "n_hops", "enc_hidden", "emb", "dec_hidden")] + [
+        (n, C.c_void_p) for n in ("enc_w1t", "enc_b1", "enc_w2t", "enc_b2", "attn_wt", "gcn_w", "gcn_b", "dec_w1t",
+                                  "dec_b1", "dec_w2t", "dec_b2")]
+
+
+# every symbol include/commarl.h declares, with its signature
+_SIGNATURES = {
+    "cm_abi_version": (C.c_int, []),
+    "cm_last_error": (C.c_char_p, []),
+    "cm_env_create": (C.c_int, [C.POINTER(EnvCfg), C.POINTER(C.c_void_p)]),
+    "cm_env_destroy": (C.c_int, [C.c_void_p]),
+    "cm_env_obs_dim": (C.c_int, [C.c_void_p]),
+    "cm_env_n_empty_cells": (C.c_int, [C.c_void_p]),
+    "cm_env_adj_is_const": (C.c_int, [C.c_void_p]),
+    "cm_env_channels_are_const": (C.c_int, [C.c_void_p]),
+    "cm_env_fill_constants": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cm_env_reset": (C.c_int, [C.c_void_p, C.POINTER(RngTape), C.POINTER(StepOut), C.c_void_p]),
+    "cm_env_step": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(RngTape), C.POINTER(StepOut), C.c_void_p]),
+    "cm_env_status": (C.c_int, [C.c_void_p]),
+    "cm_env_get_state": (C.c_int, [C.c_void_p, C.POINTER(EnvState)]),
+    "cm_env_set_state": (C.c_int, [C.c_void_p, C.POINTER(EnvState)]),
+    "cm_policy_forward": (C.c_int, [C.POINTER(PolicyWeights), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_uint64, C.c_int32, C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p]),
+    "cm_critic_forward": (C.c_int, [C.POINTER(CriticWeights), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p]),
+    "cm_masked_agg_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cm_masked_agg_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p]),
+    "cm_discount_returns": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p,
+                                      C.c_void_p]),
+    "cm_gae": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int32,
+                         C.c_float, C.c_void_p, C.c_void_p]),
+}
+EXPORTED = tuple(_SIGNATURES)
+
+_lib = None
+
+
+class CommarlError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library.  Fails loudly when the HIP extension is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CommarlError(
+                f"{LIB_PATH} not found: build it with `make -C com-marl_amd/csrc` (or __graft_entry__.build()). "
+                "There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)      # AttributeError if the .so does not export a declared symbol
+            fn.restype, fn.argtypes = res, args
+        if L.cm_abi_version() != 1:
+            raise CommarlError("libcommarl_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().cm_last_error()
+        raise CommarlError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """Raw device pointer of a torch tensor (or None)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "C ABI takes contiguous buffers"
+    return t.data_ptr()
+
+
+def current_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,54 @@
+// cm_internal.h - shared between the translation units of libcommarl_hip.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/commarl.h"
+
+namespace cm {
+
+int set_error(int code, const std::string &msg);   // stores thread-local text, returns code
+int hip_fail(hipError_t e, const char *what);      // -> CM_ERR_HIP
+
+#define CM_HIP(call)                                          \
+    do {                                                      \
+        hipError_t _e = (call);                               \
+        if (_e != hipSuccess) return ::cm::hip_fail(_e, #call); \
+    } while (0)
+
+// Device-side view of one batched env set (passed to kernels by value).
+struct EnvDev {
+    int scen, B, N, M, S, R, W, d, load, max_steps, mpl, L, rc2, channel, add_clock, n_empty, rng_mode, env_id_offset;
+    int adj_const, ch_const;
+    float ploss, pgb, pbg;
+    double cap_rew, step_cost, move_cost, penalty, lazy, revisit, final_reward;
+    uint32_t key0, key1;
+    // SoA state in HBM
+    int2 *agent_pos;          // [B,N]  (row, col)
+    int2 *prey_pos;           // [B,M]
+    uint8_t *alive;           // [B,M]
+    uint32_t *visited;        // [B,S]  row bitmasks (CO)
+    int32_t *step_count;      // [B]
+    int32_t *total_capture;   // [B]
+    int32_t *success;         // [B]
+    uint8_t *ge_state;        // [B,N,N]
+    uint32_t *rng_step;       // [B]
+    int32_t *status;          // [1] first kernel-side error
+    // read-only tables
+    const uint8_t *base_grid; // [S*S] CO walls (0 empty / 3 wall)
+    const float *lut_row;     // [S]   obs row coordinate
+    const float *lut_col;     // [S]
+    const float *lut_step;    // [max_steps+1] clock
+};
+
+}  // namespace cm
+
+struct cm_env {
+    cm_env_cfg cfg;
+    cm::EnvDev dev;
+    size_t lds_bytes;
+    void *arena;              // one hipMalloc for all state
+    size_t arena_bytes;
+};

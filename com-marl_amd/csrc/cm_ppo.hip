@@ -1,0 +1,275 @@
+// cm_ppo.hip - PPO-update side kernels (gfx950):
+//   * cm_masked_agg_forward/backward : the adjacency-masked GCN aggregation as one fused op for
+//     the autograd path  (com_marl/torch/modules/comm_base_net.py:99-105 +
+//     graph_conv_module.py:63-70):  A = M*R*C ; A /= rowsum + 1e-12 ; out = tanh(A.(HW) + b)
+//   * cm_discount_returns             : garage/misc/tensor_utils.py:7-23 (f64 recurrence)
+//   * cm_gae                          : garage/torch/algos/_utils.py:56-113 + the per-path
+//                                       normalisation of centralized_ma_ppo.py:422-426
+// Samples are [P*T] env states; a 256-thread workgroup owns EPB whole samples so that the
+// N x N mask tile and the N x 64 feature tile are read from HBM exactly once.
+#include <algorithm>
+
+#include "cm_internal.h"
+
+namespace cm {
+
+constexpr int TPB = 256;
+constexpr int RC = 4;
+
+__host__ __device__ inline int agg_epb(int N) { return (N % RC == 0) ? (48 / N > 0 ? 48 / N : 1) : 1; }
+
+// LDS: A [rows][NP], HW [rows][SE], (bwd: dP [rows][SE], dA [rows][NP], mask [rows][NP], den [rows])
+template <int E>
+__global__ __launch_bounds__(TPB) void agg_fwd_kernel(int S, int N, int EPB, const float *__restrict__ attn,
+                                                     const float *__restrict__ adj, const float *__restrict__ chan,
+                                                     long ch_stride, const float *__restrict__ hw,
+                                                     const float *__restrict__ bias, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int SE = E + 4;
+    const int tid = threadIdx.x, NN = N * N, NP = N | 1, rows_max = EPB * N;
+    float *A = lds, *HW = A + (size_t)rows_max * NP;
+    for (int s0 = blockIdx.x * EPB; s0 < S; s0 += gridDim.x * EPB) {
+        const int envs = min(EPB, S - s0), rows = envs * N;
+        for (int k = tid; k < envs * NN; k += TPB) {
+            const int e = k / NN, ij = k - e * NN, r = k / N, j = k - r * N;
+            float v = attn[(size_t)s0 * NN + k];
+            if (adj) v *= adj[(size_t)s0 * NN + k];
+            if (chan) v *= chan[(size_t)(s0 + e) * ch_stride + ij];
+            A[(size_t)r * NP + j] = v;
+        }
+        for (int k = tid; k < rows * E; k += TPB) { const int r = k / E, o = k - r * E; HW[(size_t)r * SE + o] = hw[(size_t)s0 * N * E + k]; }
+        __syncthreads();
+        for (int r = tid; r < rows; r += TPB) {
+            float *ar = A + (size_t)r * NP;
+            float sum = 0.0f;
+            for (int j = 0; j < N; ++j) sum += ar[j];
+            const float den = sum + 1e-12f;
+            for (int j = 0; j < N; ++j) ar[j] = ar[j] / den;
+        }
+        __syncthreads();
+        const int o = tid % E, rg = tid / E;
+        const float bv = bias ? bias[o] : 0.0f;
+        for (int r0 = rg * RC; r0 < rows; r0 += (TPB / E) * RC) {
+            const int e = r0 / N;
+            const float *h = HW + (size_t)e * N * SE + o;
+            float acc[RC] = { 0.0f, 0.0f, 0.0f, 0.0f };
+            const float *ar[RC];
+#pragma unroll
+            for (int i = 0; i < RC; ++i) ar[i] = A + (size_t)min(r0 + i, rows - 1) * NP;
+            for (int j = 0; j < N; ++j) {
+                const float hv = h[(size_t)j * SE];
+#pragma unroll
+                for (int i = 0; i < RC; ++i) acc[i] = fmaf(ar[i][j], hv, acc[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < RC; ++i)
+                if (r0 + i < rows && (r0 + i) / N == e) out[((size_t)s0 * N + r0 + i) * E + o] = tanhf(acc[i] + bv);
+        }
+        __syncthreads();
+    }
+}
+
+template <int E>
+__global__ __launch_bounds__(TPB) void agg_bwd_kernel(int S, int N, int EPB, const float *__restrict__ attn,
+                                                     const float *__restrict__ adj, const float *__restrict__ chan,
+                                                     long ch_stride, const float *__restrict__ hw,
+                                                     const float *__restrict__ outv, const float *__restrict__ d_out,
+                                                     float *__restrict__ d_attn, float *__restrict__ d_hw,
+                                                     float *__restrict__ d_bias) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int SE = E + 4;
+    const int tid = threadIdx.x, NN = N * N, NP = N | 1, rows_max = EPB * N;
+    float *A = lds;                                   // normalised A
+    float *MK = A + (size_t)rows_max * NP;            // mask product R*C
+    float *DA = MK + (size_t)rows_max * NP;           // dL/dA
+    float *HW = DA + (size_t)rows_max * NP;           // [rows][SE]
+    float *DP = HW + (size_t)rows_max * SE;           // dL/d(pre-activation) [rows][SE]
+    float *den = DP + (size_t)rows_max * SE;          // [rows]
+    float *dbs = den + rows_max;                      // [TPB/E][E] partial bias grads
+    const int o = tid % E, rg = tid / E;
+    float dbias_acc = 0.0f;
+    for (int s0 = blockIdx.x * EPB; s0 < S; s0 += gridDim.x * EPB) {
+        const int envs = min(EPB, S - s0), rows = envs * N;
+        for (int k = tid; k < envs * NN; k += TPB) {
+            const int e = k / NN, ij = k - e * NN, r = k / N, j = k - r * N;
+            float m = 1.0f;
+            if (adj) m *= adj[(size_t)s0 * NN + k];
+            if (chan) m *= chan[(size_t)(s0 + e) * ch_stride + ij];
+            MK[(size_t)r * NP + j] = m;
+            A[(size_t)r * NP + j] = attn[(size_t)s0 * NN + k] * m;
+        }
+        for (int k = tid; k < rows * E; k += TPB) {
+            const int r = k / E, c = k - r * E;
+            const size_t g = (size_t)s0 * N * E + k;
+            HW[(size_t)r * SE + c] = hw[g];
+            const float y = outv[g];
+            const float dp = d_out[g] * (1.0f - y * y);          // tanh'
+            DP[(size_t)r * SE + c] = dp;
+        }
+        __syncthreads();
+        for (int r = tid; r < rows; r += TPB) {
+            float *ar = A + (size_t)r * NP;
+            float sum = 0.0f;
+            for (int j = 0; j < N; ++j) sum += ar[j];
+            const float dn = sum + 1e-12f;
+            den[r] = dn;
+            for (int j = 0; j < N; ++j) ar[j] = ar[j] / dn;
+        }
+        // bias grad partial: column o over this thread's row group
+        for (int r = rg; r < rows; r += TPB / E) dbias_acc += DP[(size_t)r * SE + o];
+        __syncthreads();
+        // d_hw[j][o] = sum_i A[i][j] * dP[i][o]   (rows i of the same sample)
+        for (int r0 = rg * RC; r0 < rows; r0 += (TPB / E) * RC) {
+            const int e = r0 / N;
+            float acc[RC] = { 0.0f, 0.0f, 0.0f, 0.0f };
+            for (int i = 0; i < N; ++i) {
+                const float dpv = DP[(size_t)(e * N + i) * SE + o];
+                const float *ai = A + (size_t)(e * N + i) * NP;
+#pragma unroll
+                for (int q = 0; q < RC; ++q) {
+                    const int j = min(r0 + q, rows - 1) - e * N;
+                    if (j < N) acc[q] = fmaf(ai[j], dpv, acc[q]);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < RC; ++q)
+                if (r0 + q < rows && (r0 + q) / N == e) d_hw[((size_t)s0 * N + r0 + q) * E + o] = acc[q];
+        }
+        // dA[i][j] = sum_o dP[i][o] * HW[j][o]
+        for (int k = tid; k < envs * NN; k += TPB) {
+            const int e = k / NN, ij = k - e * NN, i = ij / N, j = ij - i * N;
+            const float4 *x = reinterpret_cast<const float4 *>(DP + (size_t)(e * N + i) * SE);
+            const float4 *y = reinterpret_cast<const float4 *>(HW + (size_t)(e * N + j) * SE);
+            float acc = 0.0f;
+#pragma unroll
+            for (int c = 0; c < E / 4; ++c) {
+                const float4 u = x[c], v = y[c];
+                acc = fmaf(u.x, v.x, acc); acc = fmaf(u.y, v.y, acc); acc = fmaf(u.z, v.z, acc); acc = fmaf(u.w, v.w, acc);
+            }
+            DA[(size_t)(e * N + i) * NP + j] = acc;
+        }
+        __syncthreads();
+        // through the renormalisation: dM_ij = mask_ij * (dA_ij - sum_k dA_ik A_ik) / den_i
+        for (int r = tid; r < rows; r += TPB) {
+            const float *ar = A + (size_t)r * NP, *da = DA + (size_t)r * NP, *mk = MK + (size_t)r * NP;
+            float t = 0.0f;
+            for (int j = 0; j < N; ++j) t = fmaf(da[j], ar[j], t);
+            const float inv = 1.0f / den[r];
+            float *dst = d_attn + ((size_t)s0 * N + r) * N;
+            for (int j = 0; j < N; ++j) dst[j] = mk[j] * (da[j] - t) * inv;
+        }
+        __syncthreads();
+    }
+    if (d_bias) {
+        dbs[rg * E + o] = dbias_acc;
+        __syncthreads();
+        if (rg == 0) {
+            float v = 0.0f;
+            for (int q = 0; q < TPB / E; ++q) v += dbs[q * E + o];
+            atomicAdd(d_bias + o, v);
+        }
+    }
+}
+
+__global__ void returns_kernel(int P, int T, const double *__restrict__ rewards, const int32_t *__restrict__ lens,
+                               double gamma, float *__restrict__ returns) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const int n = lens ? lens[p] : T;
+    double y = 0.0;
+    for (int t = T - 1; t >= 0; --t) {
+        if (t < n) { y = rewards[(size_t)p * T + t] + gamma * y; returns[(size_t)p * T + t] = (float)y; }
+        else returns[(size_t)p * T + t] = 0.0f;
+    }
+}
+
+// delta_t = r_t + g V_{t+1} - V_t over the PADDED length (V past the end = 0), A_t = delta_t + g*lam*A_{t+1};
+// optional per-path normalisation over the first lens[p] steps, biased variance, applied to the whole row.
+__global__ void gae_kernel(int P, int T, const float *__restrict__ rewards, const float *__restrict__ baselines,
+                           const int32_t *__restrict__ lens, float gamma, float lam, int normalize, float eps,
+                           float *__restrict__ adv) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const float *r = rewards + (size_t)p * T, *v = baselines + (size_t)p * T;
+    float *a = adv + (size_t)p * T;
+    const double gl = (double)(gamma * lam);
+    double acc = 0.0, vnext = 0.0;
+    for (int t = T - 1; t >= 0; --t) {
+        const float delta = (r[t] + gamma * (float)vnext) - v[t];       // f32 like the reference's tensor expression
+        acc = (double)delta + gl * acc;
+        a[t] = (float)acc;
+        vnext = v[t];
+    }
+    if (!normalize) return;
+    const int n = lens ? lens[p] : T;
+    if (n <= 0) return;
+    double s = 0.0;
+    for (int t = 0; t < n; ++t) s += a[t];
+    const double mean = s / n;
+    double q = 0.0;
+    for (int t = 0; t < n; ++t) { const double dlt = a[t] - mean; q += dlt * dlt; }
+    const float m32 = (float)mean, inv = 1.0f / sqrtf((float)(q / n) + eps);
+    for (int t = 0; t < T; ++t) a[t] = (a[t] - m32) * inv;
+}
+
+}  // namespace cm
+
+using namespace cm;
+
+static size_t agg_lds_fwd(int N, int E) { const int epb = agg_epb(N), rows = epb * N; return ((size_t)rows * (N | 1) + (size_t)rows * (E + 4)) * 4; }
+static size_t agg_lds_bwd(int N, int E) {
+    const int epb = agg_epb(N), rows = epb * N;
+    return ((size_t)rows * (N | 1) * 3 + (size_t)rows * (E + 4) * 2 + rows + TPB) * 4;
+}
+
+extern "C" int cm_masked_agg_forward(int32_t S, int32_t N, int32_t E, const float *attn, const float *dist_adj,
+                                     const float *chan, int64_t ch_stride, const float *hw, const float *bias,
+                                     float *out, void *stream) {
+    if (!attn || !hw || !out) return set_error(CM_ERR_ARG, "cm_masked_agg_forward: null argument");
+    if (E != 64) return set_error(CM_ERR_ARG, "cm_masked_agg_forward: embedding dim 64 only");
+    if (S <= 0) return CM_OK;
+    const size_t lds = agg_lds_fwd(N, E);
+    if (lds > 160 * 1024) return set_error(CM_ERR_ARG, "cm_masked_agg_forward: n_agents too large");
+    static bool once = false;
+    if (!once) { CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_fwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
+    const int epb = agg_epb(N);
+    const int blocks = (int)std::min<long>((S + epb - 1) / epb, 256 * 8);
+    hipLaunchKernelGGL(agg_fwd_kernel<64>, dim3(blocks), dim3(TPB), lds, (hipStream_t)stream, S, N, epb, attn, dist_adj, chan, (long)ch_stride, hw, bias, out);
+    CM_HIP(hipGetLastError());
+    return CM_OK;
+}
+
+extern "C" int cm_masked_agg_backward(int32_t S, int32_t N, int32_t E, const float *attn, const float *dist_adj,
+                                      const float *chan, int64_t ch_stride, const float *hw, const float *out,
+                                      const float *d_out, float *d_attn, float *d_hw, float *d_bias, void *stream) {
+    if (!attn || !hw || !out || !d_out || !d_attn || !d_hw) return set_error(CM_ERR_ARG, "cm_masked_agg_backward: null argument");
+    if (E != 64) return set_error(CM_ERR_ARG, "cm_masked_agg_backward: embedding dim 64 only");
+    if (S <= 0) return CM_OK;
+    const size_t lds = agg_lds_bwd(N, E);
+    if (lds > 160 * 1024) return set_error(CM_ERR_ARG, "cm_masked_agg_backward: n_agents too large");
+    static bool once = false;
+    if (!once) { CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_bwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
+    const int epb = agg_epb(N);
+    const int blocks = (int)std::min<long>((S + epb - 1) / epb, 256 * 4);
+    hipLaunchKernelGGL(agg_bwd_kernel<64>, dim3(blocks), dim3(TPB), lds, (hipStream_t)stream, S, N, epb, attn, dist_adj, chan, (long)ch_stride, hw, out, d_out, d_attn, d_hw, d_bias);
+    CM_HIP(hipGetLastError());
+    return CM_OK;
+}
+
+extern "C" int cm_discount_returns(int32_t P, int32_t T, const double *rewards, const int32_t *lens, double gamma,
+                                   float *returns, void *stream) {
+    if (!rewards || !returns) return set_error(CM_ERR_ARG, "cm_discount_returns: null argument");
+    if (P <= 0 || T <= 0) return CM_OK;
+    hipLaunchKernelGGL(returns_kernel, dim3((P + 63) / 64), dim3(64), 0, (hipStream_t)stream, P, T, rewards, lens, gamma, returns);
+    CM_HIP(hipGetLastError());
+    return CM_OK;
+}
+
+extern "C" int cm_gae(int32_t P, int32_t T, const float *rewards, const float *baselines, const int32_t *lens,
+                      float gamma, float lam, int32_t normalize, float eps, float *adv, void *stream) {
+    if (!rewards || !baselines || !adv) return set_error(CM_ERR_ARG, "cm_gae: null argument");
+    if (P <= 0 || T <= 0) return CM_OK;
+    hipLaunchKernelGGL(gae_kernel, dim3((P + 63) / 64), dim3(64), 0, (hipStream_t)stream, P, T, rewards, baselines, lens, gamma, lam, normalize, eps, adv);
+    CM_HIP(hipGetLastError());
+    return CM_OK;
+}

@@ -1,0 +1,457 @@
+"""Comm-DP policy and critic: same classes, ctor kwargs, parameter names and numerics as the
+reference, two execution paths:
+
+  * rollout / no-grad : ONE fused HIP launch per batch of env states through the C ABI
+    (``cm_policy_forward`` / ``cm_critic_forward``, csrc/cm_policy.hip);
+  * PPO update (autograd): dense per-agent GEMMs on PyTorch-ROCm (rocBLAS / MFMA), the
+    adjacency-masked aggregation as the custom HIP op ``masked_aggregate``
+    (``cm_masked_agg_forward/backward``, csrc/cm_ppo.hip).
+
+Reference: com_marl/torch/modules/comm_base_net.py, attention_module.py, graph_conv_module.py,
+mlp_encoder_module.py, categorical_mlp_module.py, gaussian_mlp_module.py,
+policies/comm_categorical_mlp_policy.py, baselines/comm_base_critic.py,
+garage/torch/modules/multi_headed_mlp_module.py.
+"""
+import ctypes as C
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+from torch import nn
+from torch.distributions import Categorical, Normal
+
+from . import _lib as L
+
+
+# ---------------------------------------------------------------------------------------------
+# building blocks with the reference's state_dict names
+# ---------------------------------------------------------------------------------------------
+class _Tanh(nn.Module):
+    def forward(self, x):
+        return torch.tanh(x)
+
+
+class MLPModule(nn.Module):
+    """garage MultiHeadedMLPModule with one head (multi_headed_mlp_module.py:54-149):
+    ``_layers.{i}.linear`` (+tanh) then ``_output_layers.0.linear`` (+ optional nonlinearity).
+    Init order mirrors the reference: nn.Linear default init, then xavier_uniform_ / zeros_."""
+
+    def __init__(self, input_dim, output_dim, hidden_sizes, output_tanh=False):
+        super().__init__()
+        self._layers = nn.ModuleList()
+        prev = input_dim
+        for size in hidden_sizes:
+            lin = nn.Linear(prev, size)
+            nn.init.xavier_uniform_(lin.weight)
+            nn.init.zeros_(lin.bias)
+            self._layers.append(nn.Sequential(OrderedDict(linear=lin, non_linearity=_Tanh())))
+            prev = size
+        lin = nn.Linear(prev, output_dim)
+        nn.init.xavier_uniform_(lin.weight)
+        nn.init.zeros_(lin.bias)
+        mods = OrderedDict(linear=lin)
+        if output_tanh:
+            mods["non_linearity"] = _Tanh()
+        self._output_layers = nn.ModuleList([nn.Sequential(mods)])
+
+    def forward(self, x):
+        for layer in self._layers:
+            x = layer(x)
+        return self._output_layers[0](x)
+
+
+class AttentionModule(nn.Module):
+    """'general' attention (attention_module.py:17-51): softmax_j((q W^T) . k_j)."""
+
+    def __init__(self, dimensions, attention_type="general"):
+        super().__init__()
+        if attention_type != "general":
+            raise NotImplementedError("only attention_type='general' (the runners' default) is built")
+        self.attention_type = attention_type
+        self.linear_in = nn.Linear(dimensions, dimensions, bias=False)
+
+    def forward(self, query):
+        scores = torch.matmul(self.linear_in(query), query.transpose(-2, -1))
+        return torch.softmax(scores, dim=-1)
+
+
+class GraphConvolutionModule(nn.Module):
+    """graph_conv_module.py:24-72: weight [in,out] ~ U(+-1/sqrt(out)), bias likewise."""
+
+    def __init__(self, in_features, out_features, bias=True, id=None):
+        super().__init__()
+        self.in_features, self.out_features, self.id = in_features, out_features, id
+        self.weight = nn.Parameter(torch.empty(in_features, out_features))
+        self.bias = nn.Parameter(torch.empty(out_features)) if bias else None
+        stdv = 1.0 / math.sqrt(out_features)
+        with torch.no_grad():
+            self.weight.uniform_(-stdv, stdv)
+            if self.bias is not None:
+                self.bias.uniform_(-stdv, stdv)
+
+
+class _MaskedAggregate(torch.autograd.Function):
+    """out = tanh(A.(HW) + b), A = M*R*C row-renormalised (comm_base_net.py:101-103,
+    graph_conv_module.py:63-70) as one HIP kernel each way."""
+
+    @staticmethod
+    def forward(ctx, attn, dist_adj, chan_all, hop, hw, bias):
+        S, N, E = hw.shape
+        attn, hw = attn.contiguous(), hw.contiguous()
+        out = torch.empty_like(hw)
+        chan_ptr, stride = None, 0
+        if chan_all is not None:
+            Lh = chan_all.shape[1]
+            chan_ptr, stride = chan_all.data_ptr() + 4 * hop * N * N, Lh * N * N
+        with torch.cuda.device(hw.device):
+            L.check(L.lib().cm_masked_agg_forward(S, N, E, L.ptr(attn), L.ptr(dist_adj), chan_ptr, stride, L.ptr(hw),
+                                                  L.ptr(bias), L.ptr(out), L.current_stream()), "cm_masked_agg_forward")
+        ctx.save_for_backward(attn, dist_adj, chan_all, hw, out)
+        ctx.hop, ctx.has_bias = hop, bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        attn, dist_adj, chan_all, hw, out = ctx.saved_tensors
+        S, N, E = hw.shape
+        d_out = d_out.contiguous()
+        d_attn, d_hw = torch.empty_like(attn), torch.empty_like(hw)
+        d_bias = torch.zeros(E, dtype=hw.dtype, device=hw.device) if ctx.has_bias else None
+        chan_ptr, stride = None, 0
+        if chan_all is not None:
+            chan_ptr, stride = chan_all.data_ptr() + 4 * ctx.hop * N * N, chan_all.shape[1] * N * N
+        with torch.cuda.device(hw.device):
+            L.check(L.lib().cm_masked_agg_backward(S, N, E, L.ptr(attn), L.ptr(dist_adj), chan_ptr, stride, L.ptr(hw),
+                                                   L.ptr(out), L.ptr(d_out), L.ptr(d_attn), L.ptr(d_hw),
+                                                   L.ptr(d_bias), L.current_stream()), "cm_masked_agg_backward")
+        return d_attn, None, None, None, d_hw, d_bias
+
+
+def masked_aggregate(attn, dist_adj, channels, hop, hw, bias):
+    """attn [S,N,N], dist_adj [S,N,N] or None (= ones), channels [S,L,N,N] or None, hw [S,N,E]."""
+    if not hw.is_cuda:
+        raise L.CommarlError("masked_aggregate is a HIP op: tensors must live on the MI355X (no CPU fallback)")
+    return _MaskedAggregate.apply(attn, dist_adj, channels, hop, hw, bias)
+
+
+# ---------------------------------------------------------------------------------------------
+# trunk
+# ---------------------------------------------------------------------------------------------
+def _as_dev(x, device):
+    if x is None:
+        return None
+    if not torch.is_tensor(x):
+        x = torch.as_tensor(np.asarray(x), dtype=torch.float32)
+    return x.to(device=device, dtype=torch.float32)
+
+
+class CommBaseNet(nn.Module):
+    """comm_base_net.py:11-111."""
+
+    def __init__(self, env_spec, n_agents, encoder_hidden_sizes=(128,), embedding_dim=64, attention_type="general",
+                 n_gcn_layers=2, gcn_bias=True, state_include_actions=False, name="comm_base", residual=True,
+                 device="cpu"):
+        super().__init__()
+        self.residual, self.device, self._n_agents, self.name = residual, device, n_agents, name
+        self.comm = True
+        self.centralized = True
+        self.step = 0
+        self.eps = 1e-12
+        self._cent_obs_dim = env_spec.observation_space.flat_dim
+        self._dec_obs_dim = int(self._cent_obs_dim / n_agents)
+        self._action_dim = env_spec.action_space.n
+        self._embedding_dim = embedding_dim
+        self.n_gcn_layers = n_gcn_layers
+        if state_include_actions:
+            self._dec_obs_dim += self._action_dim
+        self.encoder = MLPModule(self._dec_obs_dim, embedding_dim, encoder_hidden_sizes, output_tanh=True)
+        self.attention_layer = AttentionModule(embedding_dim, attention_type)
+        self.gcn_layers = nn.ModuleList([GraphConvolutionModule(embedding_dim, embedding_dim, bias=gcn_bias, id=i)
+                                         for i in range(n_gcn_layers)])
+        self._enc_hidden = tuple(encoder_hidden_sizes)
+        self._pack_sig, self._pack = None, None
+
+    # -- helpers --------------------------------------------------------------------------------
+    def grad_norm(self):
+        return float(np.sqrt(np.sum([p.grad.norm(2).item() ** 2 for p in self.parameters() if p.grad is not None])))
+
+    def reset(self, dones=None):
+        return
+
+    @property
+    def recurrent(self):
+        return False
+
+    def _flatten(self, obs_n, dist_adj, channels):
+        """Reference reshapes (comm_categorical_mlp_policy.py:56-71): obs [...,N*d] -> [S,N,d],
+        dist_adj [...,N*N]|[...,N,N] -> [S,N,N], channels [...,L*N,N]|[...,L,N,N] -> [S,L,N,N]."""
+        N, Lh = self._n_agents, len(self.gcn_layers)
+        lead = obs_n.shape[:-1] if obs_n.shape[-1] == N * self._dec_obs_dim else obs_n.shape[:-2]
+        S = int(np.prod(lead)) if len(lead) else 1
+        obs = obs_n.reshape(S, N, self._dec_obs_dim)
+        adj = None if dist_adj is None else dist_adj.reshape(S, N, N)
+        ch = None if channels is None else channels.reshape(S, Lh, N, N)
+        return lead, S, obs, adj, ch
+
+    def trunk(self, obs, adj, ch):
+        """obs [S,N,d] -> (E, H_L, M) with autograd (CommBaseNet.forward :80-108)."""
+        E = self.encoder(obs)
+        M = self.attention_layer(E)
+        H = E
+        for l, g in enumerate(self.gcn_layers):
+            H = masked_aggregate(M, adj, ch, l, torch.matmul(H, g.weight), g.bias)
+        return E, H, M
+
+    # -- weight pack for the fused C-ABI forward -----------------------------------------------
+    def _trunk_tensors(self):
+        enc = self.encoder
+        if len(enc._layers) != 1:
+            raise L.CommarlError("fused forward is built for one encoder hidden layer (the runners' default)")
+        t = OrderedDict()
+        t["enc_w1t"] = enc._layers[0].linear.weight.t()
+        t["enc_b1"] = enc._layers[0].linear.bias
+        t["enc_w2t"] = enc._output_layers[0].linear.weight.t()
+        t["enc_b2"] = enc._output_layers[0].linear.bias
+        t["attn_wt"] = self.attention_layer.linear_in.weight.t()
+        t["gcn_w"] = torch.stack([g.weight for g in self.gcn_layers]) if len(self.gcn_layers) else None
+        t["gcn_b"] = (torch.stack([g.bias for g in self.gcn_layers])
+                      if len(self.gcn_layers) and self.gcn_layers[0].bias is not None else None)
+        return t
+
+    def _head_tensors(self):
+        raise NotImplementedError
+
+    def _packed(self):
+        """Flat contiguous device copy of the (transposed) weights, rebuilt when any parameter changed."""
+        sig = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if sig != self._pack_sig:
+            with torch.no_grad():
+                ts = self._trunk_tensors()
+                ts.update(self._head_tensors())
+                flat, offs, off = [], {}, 0
+                for k, v in ts.items():
+                    if v is None:
+                        offs[k] = None
+                        continue
+                    v = v.detach().to(torch.float32).contiguous().reshape(-1)
+                    pad = (-v.numel()) % 4                      # keep every tensor 16-byte aligned
+                    offs[k] = off
+                    flat.append(v)
+                    if pad:
+                        flat.append(torch.zeros(pad, dtype=torch.float32, device=v.device))
+                    off += v.numel() + pad
+                buf = torch.cat(flat)
+                base = buf.data_ptr()
+                self._pack = (buf, {k: (None if o is None else base + 4 * o) for k, o in offs.items()})
+                self._pack_sig = sig
+        return self._pack[1]
+
+
+# ---------------------------------------------------------------------------------------------
+# policy
+# ---------------------------------------------------------------------------------------------
+class CommCategoricalMLPPolicy(CommBaseNet):
+    """comm_categorical_mlp_policy.py:8-141 (same ctor kwargs as runner_pp_commDP.py:49-61)."""
+
+    def __init__(self, env_spec, n_agents, encoder_hidden_sizes=(128,), embedding_dim=64, attention_type="general",
+                 n_gcn_layers=2, residual=True, gcn_bias=True, categorical_mlp_hidden_sizes=(128, 64, 32),
+                 name="comm_categorical_mlp_policy", device="cpu"):
+        super().__init__(env_spec=env_spec, n_agents=n_agents, encoder_hidden_sizes=encoder_hidden_sizes,
+                         embedding_dim=embedding_dim, attention_type=attention_type, n_gcn_layers=n_gcn_layers,
+                         gcn_bias=gcn_bias, name=name, device=device)
+        self.residual = residual
+        self._head_sizes = tuple(categorical_mlp_hidden_sizes)
+        self.categorical_output_layer = MLPModule(embedding_dim, self._action_dim, categorical_mlp_hidden_sizes)
+        self.seed, self.env_id_offset, self._policy_step = 1, 0, 0
+        self.to(device)
+
+    # -- autograd path (PPO update) --------------------------------------------------------------
+    def _probs(self, obs_n, avail_actions_n, dist_adj, channels):
+        lead, S, obs, adj, ch = self._flatten(obs_n, dist_adj, channels)
+        E, H, M = self.trunk(obs, adj, ch)
+        x = E + H if self.residual else H
+        logits = self.categorical_output_layer(x)
+        probs = torch.softmax(logits, dim=-1)
+        if avail_actions_n is not None:
+            probs = probs * avail_actions_n.reshape(S, self._n_agents, -1)
+        probs = probs / probs.sum(dim=-1, keepdim=True)
+        N = self._n_agents
+        return probs.reshape(*lead, N, -1), M.reshape(*lead, N, N)
+
+    def forward(self, obs_n, avail_actions_n, dist_adj, channels, get_actions=False):
+        """-> (Categorical over [..., N, A], attention [..., N, N]).  get_actions=True takes
+        numpy inputs and runs the fused no-grad kernel (reference :56-62,81-96)."""
+        dev = next(self.parameters()).device
+        if get_actions:
+            obs_n, avail_actions_n = _as_dev(obs_n, dev), _as_dev(avail_actions_n, dev)
+            dist_adj, channels = _as_dev(dist_adj, dev), _as_dev(channels, dev)
+            _, probs, attn = self.act_device(obs_n, avail_actions_n, dist_adj, channels, want_actions=False)
+            return Categorical(probs=probs.cpu()), attn.cpu()
+        probs, attn = self._probs(obs_n, avail_actions_n, dist_adj, channels)
+        return Categorical(probs=probs), attn
+
+    def entropy(self, observations, avail_actions, dist_adj, channels):
+        dists_n, _ = self.forward(observations, avail_actions, dist_adj, channels)
+        return dists_n.entropy().mean(axis=-1)                       # :121-126
+
+    def log_likelihood(self, observations, avail_actions, dist_adj, channels, actions):
+        dists_n, _ = self.forward(observations, avail_actions, dist_adj, channels)
+        return dists_n.log_prob(actions).sum(axis=-1)                # :128-137
+
+    # -- fused rollout path ----------------------------------------------------------------------
+    def _head_tensors(self):
+        h = self.categorical_output_layer
+        if len(h._layers) != 3:
+            raise L.CommarlError("fused forward is built for the 3-hidden-layer categorical head (runner default)")
+        t = OrderedDict()
+        for i in range(3):
+            t[f"hd_w{i + 1}t"] = h._layers[i].linear.weight.t()
+            t[f"hd_b{i + 1}"] = h._layers[i].linear.bias
+        t["hd_w4t"] = h._output_layers[0].linear.weight.t()
+        t["hd_b4"] = h._output_layers[0].linear.bias
+        return t
+
+    def _weights_struct(self):
+        p = self._packed()
+        w = L.PolicyWeights()
+        w.d, w.n_agents, w.n_hops = self._dec_obs_dim, self._n_agents, len(self.gcn_layers)
+        w.enc_hidden, w.emb = self._enc_hidden[0], self._embedding_dim
+        w.h1, w.h2, w.h3 = self._head_sizes
+        w.n_act = self._action_dim
+        for k, v in p.items():
+            setattr(w, k, v)
+        return w
+
+    def set_rng(self, seed, env_id_offset=0):
+        """Philox stream of the action sampler: counter (env id, policy step, site 7, agent)."""
+        self.seed, self.env_id_offset = int(seed), int(env_id_offset)
+
+    @torch.no_grad()
+    def act_device(self, obs, avail, dist_adj, channels, greedy=False, want_actions=True, want_probs=True,
+                   want_attn=True, out_actions=None, out_probs=None, out_attn=None, policy_step=None):
+        """Fused forward on device tensors: obs [S,N*d]|[S,N,d]; avail/dist_adj/channels may be None
+        (= all ones).  Returns (actions int32 [S,N], probs [S,N,A], attn [S,N,N]) as CUDA tensors."""
+        dev = obs.device
+        if dev.type != "cuda":
+            raise L.CommarlError("the rollout forward is a HIP kernel: inputs must be CUDA tensors (no CPU fallback)")
+        N, A = self._n_agents, self._action_dim
+        S = obs.numel() // (N * self._dec_obs_dim)
+        obs = obs.contiguous()
+        actions = out_actions if out_actions is not None else (
+            torch.empty(S, N, dtype=torch.int32, device=dev) if want_actions else None)
+        probs = out_probs if out_probs is not None else (
+            torch.empty(S, N, A, dtype=torch.float32, device=dev) if want_probs else None)
+        attn = out_attn if out_attn is not None else (
+            torch.empty(S, N, N, dtype=torch.float32, device=dev) if want_attn else None)
+        if policy_step is None:
+            policy_step = self._policy_step
+            self._policy_step += 1
+        w = self._weights_struct()
+        with torch.cuda.device(dev):
+            L.check(L.lib().cm_policy_forward(
+                C.byref(w), S, L.ptr(obs), L.ptr(None if avail is None else avail.contiguous()),
+                L.ptr(None if dist_adj is None else dist_adj.contiguous()),
+                L.ptr(None if channels is None else channels.contiguous()), self.seed, self.env_id_offset,
+                policy_step & 0xFFFFFFFF, int(greedy), L.ptr(actions), L.ptr(probs), L.ptr(attn),
+                L.current_stream()), "cm_policy_forward")
+        return actions, probs, attn
+
+    def get_actions(self, obs_n, avail_actions_n, dist_adj, channels, greedy=False):
+        """numpy in / numpy out, as the reference sampler calls it (:98-119)."""
+        dev = next(self.parameters()).device
+        obs = _as_dev(obs_n, dev)
+        S = obs.shape[0]
+        act, probs, attn = self.act_device(obs.reshape(S, -1), _as_dev(avail_actions_n, dev), _as_dev(dist_adj, dev),
+                                           _as_dev(channels, dev), greedy=greedy)
+        probs, attn = probs.cpu().numpy(), attn.cpu().numpy()
+        infos = dict(action_probs=[probs[i] for i in range(S)], attention_weights=[attn[i] for i in range(S)])
+        return act.cpu().numpy().astype(np.int64), infos
+
+
+# ---------------------------------------------------------------------------------------------
+# critic
+# ---------------------------------------------------------------------------------------------
+class GaussianMLPModule(nn.Module):
+    """gaussian_mlp_module.py:62-188 in the configuration the critic uses: learned shared
+    log-std ``_init_std`` (init log 1.0), min_std 1e-6, exp parameterisation."""
+
+    def __init__(self, input_dim, output_dim, hidden_sizes=(32, 32), init_std=1.0, min_std=1e-6):
+        super().__init__()
+        self._init_std = nn.Parameter(torch.Tensor([init_std]).log())
+        self._min_std_param = math.log(min_std)
+        self._mean_module = MLPModule(input_dim, output_dim, hidden_sizes)
+
+    def forward(self, x):
+        mean = self._mean_module(x)
+        std = self._init_std.clamp(min=self._min_std_param).exp()
+        return mean, std
+
+
+class CommBaseCritic(CommBaseNet):
+    """comm_base_critic.py:11-122, aggregator 'sum' (same ctor kwargs as runner_pp_commDP.py:63-74)."""
+
+    def __init__(self, env_spec, n_agents, encoder_hidden_sizes=(128,), embedding_dim=64, decoder_hidden_sizes=(64,),
+                 attention_type="general", n_gcn_layers=2, residual=True, gcn_bias=True, share_std=False,
+                 state_include_actions=False, aggregator_type="sum", name="base_critic", device="cpu"):
+        super().__init__(env_spec=env_spec, n_agents=n_agents, encoder_hidden_sizes=encoder_hidden_sizes,
+                         embedding_dim=embedding_dim, attention_type=attention_type, n_gcn_layers=n_gcn_layers,
+                         residual=residual, gcn_bias=gcn_bias, state_include_actions=state_include_actions, name=name,
+                         device=device)
+        if aggregator_type != "sum":
+            raise NotImplementedError("only aggregator_type='sum' (the runners' default) is built")
+        self.aggregator_type = aggregator_type
+        self._dec_hidden = tuple(decoder_hidden_sizes)
+        self.baseline_aggregator = GaussianMLPModule(embedding_dim, 1, hidden_sizes=decoder_hidden_sizes)
+        self.to(device)
+
+    def _head_tensors(self):
+        m = self.baseline_aggregator._mean_module
+        if len(m._layers) != 1:
+            raise L.CommarlError("fused critic forward is built for one decoder hidden layer (default)")
+        return OrderedDict(dec_w1t=m._layers[0].linear.weight.t(), dec_b1=m._layers[0].linear.bias,
+                           dec_w2t=m._output_layers[0].linear.weight.t(), dec_b2=m._output_layers[0].linear.bias)
+
+    def _values_grad(self, obs_n, dist_adj, channels):
+        lead, S, obs, adj, ch = self._flatten(obs_n, dist_adj, channels)
+        E, H, _ = self.trunk(obs, adj, ch)
+        x = E + H if self.residual else H
+        mean, std = self.baseline_aggregator(x)
+        return mean.squeeze(-1).sum(-1).reshape(*lead), std
+
+    @torch.no_grad()
+    def values_device(self, obs, dist_adj, channels, out=None):
+        """Fused no-grad forward (cm_critic_forward): obs [..., N*d] CUDA -> values [...]."""
+        dev = obs.device
+        if dev.type != "cuda":
+            raise L.CommarlError("critic forward is a HIP kernel: inputs must be CUDA tensors (no CPU fallback)")
+        N = self._n_agents
+        lead = obs.shape[:-1] if obs.shape[-1] == N * self._dec_obs_dim else obs.shape[:-2]
+        S = obs.numel() // (N * self._dec_obs_dim)
+        values = out if out is not None else torch.empty(S, dtype=torch.float32, device=dev)
+        p = self._packed()
+        w = L.CriticWeights()
+        w.d, w.n_agents, w.n_hops = self._dec_obs_dim, N, len(self.gcn_layers)
+        w.enc_hidden, w.emb, w.dec_hidden = self._enc_hidden[0], self._embedding_dim, self._dec_hidden[0]
+        for k, v in p.items():
+            setattr(w, k, v)
+        with torch.cuda.device(dev):
+            L.check(L.lib().cm_critic_forward(C.byref(w), S, L.ptr(obs.contiguous()),
+                                              L.ptr(None if dist_adj is None else dist_adj.contiguous()),
+                                              L.ptr(None if channels is None else channels.contiguous()),
+                                              L.ptr(values), L.current_stream()), "cm_critic_forward")
+        return values.reshape(*lead) if out is None else values
+
+    def forward(self, obs_n, avail_actions_n, dist_adj, channels, get_actions=False):
+        """-> values [P,T] (:91-114).  Under no_grad this is the fused kernel."""
+        dev = next(self.parameters()).device
+        if get_actions or not torch.is_tensor(obs_n):
+            obs_n, dist_adj, channels = _as_dev(obs_n, dev), _as_dev(dist_adj, dev), _as_dev(channels, dev)
+        if not torch.is_grad_enabled():
+            return self.values_device(obs_n, dist_adj, channels)
+        return self._values_grad(obs_n, dist_adj, channels)[0]
+
+    def compute_loss(self, obs_n, returns, dist_adj, channels, get_actions=False):
+        """Gaussian NLL with the shared learned std; padded steps are included in the mean (:59-89)."""
+        values, std = self._values_grad(obs_n, dist_adj, channels)
+        return -Normal(values, std.mean()).log_prob(returns).mean()

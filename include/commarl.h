@@ -1,0 +1,201 @@
+/*
+ * commarl.h - C ABI of libcommarl_hip.so: the MI355X (gfx950) batched rollout + GNN-PPO
+ * hot path of Com-MARL.
+ *
+ * The reference (cnuns/Com-MARL) is pure Python and has no FFI of its own; the drop-in
+ * boundary is the set of Python classes its runner scripts import by name
+ * (exp_runners/predatorprey/runner_pp_commDP.py:22-28).  Those classes are re-provided by
+ * the host package (com-marl_amd/) as thin veneers over THIS C ABI.  Each entry point
+ * below cites the reference interface it replaces (file:line relative to the reference
+ * tree).  Conventions:
+ *   - every function returns 0 on success, <0 on error; cm_last_error() gives the text;
+ *     no exception ever crosses the ABI;
+ *   - all data pointers are DEVICE pointers unless the name ends in _host; buffers are
+ *     caller-owned (torch-allocated in the Python veneer) except the env state, which the
+ *     handle owns;
+ *   - `stream` is a hipStream_t passed as void*; NULL = the default stream.  Launches are
+ *     asynchronous; nothing here synchronises except get/set_state and cm_env_status;
+ *   - one handle is not thread-safe; distinct handles are independent (one process per GPU).
+ */
+#ifndef COMMARL_H
+#define COMMARL_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CM_ABI_VERSION 1
+
+enum { CM_PP = 0, CM_CO = 1 };                                  /* scenario */
+enum { CM_CH_FC = 0, CM_CH_FL = 1, CM_CH_IID = 2, CM_CH_GE = 3 }; /* channel model */
+enum { CM_RNG_PHILOX = 0, CM_RNG_TAPE = 1 };
+
+enum {
+    CM_OK = 0,
+    CM_ERR_ARG = -1,        /* bad argument / unsupported config */
+    CM_ERR_TAPE = -2,       /* RNG tape exhausted (parity mode) */
+    CM_ERR_TAPE_PREY = -3,
+    CM_ERR_ACTION = -4,     /* action outside 0..4: predator_prey.py:255, coverage.py:347 raise */
+    CM_ERR_LOAD = -5,       /* PP load not in {2,3,4}: capv undefined (predator_prey.py:77-79) */
+    CM_ERR_HIP = -6,
+    CM_ERR_NOMEM = -7
+};
+
+/* Env configuration = the `params` dict the reference envs read
+ * (predator_prey.py:52-82, coverage.py:40-96, env_communication.py:10-75) after the arg
+ * post-processing of exp_runners/env_uitils.py:174-217. */
+typedef struct cm_env_cfg {
+    int32_t scenario;        /* CM_PP / CM_CO */
+    int32_t n_envs;          /* B independent envs owned by this handle */
+    int32_t n_agents;        /* N */
+    int32_t n_preys;         /* M (PP) */
+    int32_t grid;            /* PP: G = --map; CO: m = --map (grid side m+2 incl. wall ring) */
+    int32_t rsen;            /* --sen: window (2R+1)^2 */
+    int32_t load;            /* --cap: 2 reward_default, 3/4 reward_individual */
+    int32_t max_steps;       /* env time limit (PP max_env_steps; CO ctor max_steps=400) */
+    int32_t max_path_length; /* VecEnvExecutor truncation (vec_env_executor.py:33-34) */
+    int32_t n_hops;          /* n_gcn_layers L */
+    int32_t rcom;            /* trRcom (rule Rcom+1>=map -> fully connected applied inside) */
+    int32_t channel;         /* CM_CH_* */
+    int32_t obst_hard;       /* CO obstComplex: 0 Easy / 1 Hard */
+    int32_t add_clock;       /* CO */
+    int32_t rng_mode;        /* CM_RNG_PHILOX production / CM_RNG_TAPE parity */
+    int32_t env_id_offset;   /* global id of local env 0: rank r of k owns [r*B, (r+1)*B) */
+    float ploss, pgb, pbg;
+    float _pad;
+    double capture_reward, step_cost, move_cost, penalty, lazy_penalty, revisit_penalty, final_reward;
+    uint64_t seed;
+} cm_env_cfg;
+
+/* Recorded draws for parity mode (device pointers, any may be NULL when unused):
+ * SURVEY.md App. A-6 call sites.  slot 0 = the step's comm update, slot 1 = the reset's. */
+typedef struct cm_rng_tape {
+    const uint8_t *prey;     /* [B,M,5]  np.random.choice outcomes (predator_prey.py:401), 255 unused */
+    const int32_t *spawn;    /* [B,cap,2] random.randint pairs (predator_prey.py:156,165; coverage.py:185) */
+    int32_t spawn_cap;
+    int32_t _pad;
+    const float *iid_u;      /* [B,2,L,N,N]   torch.rand (env_communication.py:212) */
+    const float *ge_u;       /* [B,2,L,2,N,N] torch.rand (gilbert_elliot_loss_model.py:138,142) */
+} cm_rng_tape;
+
+/* What VecEnvExecutor.step returns + the env attributes the sampler reads each step
+ * (centralized_ma_on_policy_vectorized_sampler.py:123-141).  Any pointer may be NULL to
+ * skip that output; dist_adj / channels are skipped automatically when constant
+ * (fully connected / FC / FL: filled once by cm_env_fill_constants). */
+typedef struct cm_step_out {
+    float *obs;              /* [B,N,d]   next observation (reset obs where done) */
+    float *reward;           /* [B]       f32 view of the reward */
+    double *reward_f64;      /* [B]       reward as the Python float the reference produces */
+    uint8_t *done;           /* [B] */
+    int32_t *details;        /* [B,6] capture, move, penalty, lazy, revisit|watching, final (sums over agents) */
+    float *dist_adj;         /* [B,N,N] */
+    float *channels;         /* [B,L,N,N] */
+    uint8_t *prey_alive;     /* [B,M] env_infos['prey_alive'] (pre-reset) */
+    int32_t *success;        /* [B] env.success after the step */
+} cm_step_out;
+
+/* Host-side snapshot of the SoA state (for parity fixtures / checkpoints). */
+typedef struct cm_env_state {
+    int32_t *agent_pos;      /* [B,N,2] */
+    int32_t *prey_pos;       /* [B,M,2] */
+    uint8_t *prey_alive;     /* [B,M] */
+    uint32_t *visited;       /* [B,S] one bitmask per grid row (CO) */
+    int32_t *step_count;     /* [B] */
+    int32_t *total_capture;  /* [B] */
+    int32_t *success;        /* [B] */
+    uint8_t *ge_state;       /* [B,N,N] */
+    uint32_t *rng_step;      /* [B] */
+} cm_env_state;
+
+typedef struct cm_env *cm_env_t;
+
+int cm_abi_version(void);
+const char *cm_last_error(void);
+
+/* PredatorPreyWrapper(...)/CoverageWrapper(...) construction (predatorprey_wrapper.py:23-44,
+ * coverage_wrapper.py:16-33) for B envs at once. */
+int cm_env_create(const cm_env_cfg *cfg, cm_env_t *out);
+int cm_env_destroy(cm_env_t h);
+int cm_env_obs_dim(cm_env_t h);          /* d per agent */
+int cm_env_n_empty_cells(cm_env_t h);    /* coverage.py:228-230 */
+int cm_env_adj_is_const(cm_env_t h);     /* 1 when Rcom rule gives fully connected (env_communication.py:71-72) */
+int cm_env_channels_are_const(cm_env_t h);
+/* write the constant dist_adj [B,N,N] / channels [B,L,N,N] once */
+int cm_env_fill_constants(cm_env_t h, float *dist_adj, float *channels, void *stream);
+
+/* VecEnvExecutor.reset (vec_env_executor.py:47-54): reset every env, emit obs + comm state. */
+int cm_env_reset(cm_env_t h, const cm_rng_tape *tape, const cm_step_out *out, void *stream);
+/* VecEnvExecutor.step (vec_env_executor.py:19-45) over env.step (predator_prey.py:494-519,
+ * coverage.py:319-401): actions int32 [B,N]. */
+int cm_env_step(cm_env_t h, const int32_t *actions, const cm_rng_tape *tape, const cm_step_out *out, void *stream);
+/* synchronises; returns the first kernel-side error (CM_ERR_TAPE / CM_ERR_ACTION ...) or 0 */
+int cm_env_status(cm_env_t h);
+int cm_env_get_state(cm_env_t h, const cm_env_state *host);
+int cm_env_set_state(cm_env_t h, const cm_env_state *host);
+
+/* Comm-DP policy weights (device pointers), reference state_dict names in comments
+ * (SURVEY.md §8 a-16).  Linear weights are passed TRANSPOSED [in,out] (contiguous over the
+ * output index) - the veneer keeps a transposed device copy; GCN weights are already [in,out]. */
+typedef struct cm_policy_weights {
+    int32_t d, n_agents, n_hops, enc_hidden, emb, h1, h2, h3, n_act;
+    int32_t _pad;
+    const float *enc_w1t, *enc_b1;   /* encoder._layers.0.linear.{weight^T,bias}          [d,128],[128] */
+    const float *enc_w2t, *enc_b2;   /* encoder._output_layers.0.linear.*                 [128,64],[64] */
+    const float *attn_wt;            /* attention_layer.linear_in.weight^T                [64,64] */
+    const float *gcn_w, *gcn_b;      /* gcn_layers.{l}.{weight,bias}                      [L,64,64],[L,64] */
+    const float *hd_w1t, *hd_b1;     /* categorical_output_layer._layers.0.linear.*       [64,128] */
+    const float *hd_w2t, *hd_b2;     /* ..._layers.1.linear.*                             [128,64] */
+    const float *hd_w3t, *hd_b3;     /* ..._layers.2.linear.*                             [64,32] */
+    const float *hd_w4t, *hd_b4;     /* ..._output_layers.0.linear.*                      [32,5] */
+} cm_policy_weights;
+
+typedef struct cm_critic_weights {
+    int32_t d, n_agents, n_hops, enc_hidden, emb, dec_hidden;
+    const float *enc_w1t, *enc_b1, *enc_w2t, *enc_b2, *attn_wt, *gcn_w, *gcn_b;
+    const float *dec_w1t, *dec_b1;   /* baseline_aggregator._mean_module._layers.0.linear.*        [64,64] */
+    const float *dec_w2t, *dec_b2;   /* baseline_aggregator._mean_module._output_layers.0.linear.* [64,1] */
+} cm_critic_weights;
+
+/* CommCategoricalMLPPolicy.get_actions (comm_categorical_mlp_policy.py:98-119) for S env
+ * states in one fused launch: encoder -> attention -> L x (mask, renorm, GCN) -> residual ->
+ * head -> softmax x avail -> renorm -> sample (inverse CDF on the Philox stream) or argmax.
+ *   obs [S,N,d]; avail [S,N,A] or NULL (= all ones, predatorprey_wrapper.py:46-51);
+ *   dist_adj [S,N,N] or NULL (= ones); channels [S,L,N,N] or NULL (= ones);
+ *   out: actions int32 [S,N] (or NULL), probs [S,N,A] (or NULL), attn [S,N,N] (or NULL). */
+int cm_policy_forward(const cm_policy_weights *w, int32_t n_samples, const float *obs, const float *avail,
+                      const float *dist_adj, const float *channels, uint64_t seed, int32_t env_id_offset,
+                      uint32_t policy_step, int32_t greedy, int32_t *actions, float *probs, float *attn,
+                      void *stream);
+
+/* CommBaseCritic.forward (comm_base_critic.py:91-114): values [S] = sum over agents. */
+int cm_critic_forward(const cm_critic_weights *w, int32_t n_samples, const float *obs, const float *dist_adj,
+                      const float *channels, float *values, void *stream);
+
+/* Adjacency-masked aggregation, one GCN hop, for S samples (comm_base_net.py:101-105 +
+ * graph_conv_module.py:63-70):  A = M*R*C; A /= rowsum+1e-12; out = tanh(A.(HW) + b).
+ *   attn M [S,N,N]; dist_adj R [S,N,N] or NULL; channel C_l [S,N,N] with element stride
+ *   ch_stride between samples (so a [S,L,N,N] tensor can be sliced) or NULL;
+ *   hw [S,N,E]; bias [E] or NULL; out [S,N,E].  Saves nothing: backward recomputes A. */
+int cm_masked_agg_forward(int32_t S, int32_t N, int32_t E, const float *attn, const float *dist_adj,
+                          const float *chan, int64_t ch_stride, const float *hw, const float *bias, float *out,
+                          void *stream);
+/* grads of the op above: given out and d_out returns d_attn [S,N,N], d_hw [S,N,E], d_bias [E] (accumulated with
+ * atomics; caller zeroes). */
+int cm_masked_agg_backward(int32_t S, int32_t N, int32_t E, const float *attn, const float *dist_adj,
+                           const float *chan, int64_t ch_stride, const float *hw, const float *out,
+                           const float *d_out, float *d_attn, float *d_hw, float *d_bias, void *stream);
+
+/* tensor_utils.discount_cumsum (garage/misc/tensor_utils.py:7-23) per path over a padded
+ * [P,T] batch: f64 recurrence, f32 result, zero past lens[p]. */
+int cm_discount_returns(int32_t P, int32_t T, const double *rewards, const int32_t *lens, double gamma,
+                        float *returns, void *stream);
+/* compute_advantages (garage/torch/algos/_utils.py:56-113) + per-path normalisation over the
+ * valid steps (centralized_ma_ppo.py:422-426); normalize=0 skips the second part. */
+int cm_gae(int32_t P, int32_t T, const float *rewards, const float *baselines, const int32_t *lens, float gamma,
+           float lam, int32_t normalize, float eps, float *adv, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COMMARL_H */

@@ -1,0 +1,65 @@
+"""Adapters that give the HIP path (through the C ABI) the same face as oracle.OracleEnv,
+so that the parity tests replay the very same fixtures through both."""
+import numpy as np
+import torch
+
+from com_marl_amd import envs as E
+from com_marl_amd import _lib as L
+
+
+def params_from_cfg(cfg):
+    """oracle Cfg -> reference-style params dict."""
+    pp = cfg.scenario == 0
+    ch = {0: "FC", 1: "FL", 2: "IID", 3: "GE"}[cfg.channel]
+    p = dict(load=cfg.load, max_env_steps=cfg.max_path_length, capture_reward=cfg.capture_reward,
+             step_cost=abs(cfg.step_cost), rm=abs(cfg.move_cost), penalty=abs(cfg.penalty), grid_size=cfg.grid,
+             Rsen=cfg.rsen, n_agents=cfg.n_agents, n_preys=cfg.n_preys, n_gcn_layers=cfg.n_hops, mode="train",
+             trRcom=cfg.rcom, trpl=cfg.ploss, Pgb=cfg.pgb, Pbg=cfg.pbg, lazy_penalty=abs(cfg.lazy_penalty),
+             revisit_penalty=abs(cfg.revisit_penalty), obstComplex="Hard" if cfg.obst_hard else "Easy",
+             add_clock=cfg.add_clock)
+    return ("pp" if pp else "co"), p, ch
+
+
+class HipEnv:
+    """OracleEnv-shaped view of GridEnvBatch (numpy attributes refreshed after every call)."""
+
+    def __init__(self, cfg, device="cuda:0"):
+        scen, p, ch = params_from_cfg(cfg)
+        self.cfg = cfg
+        self.batch = E.GridEnvBatch(scen, p, cfg.n_envs, device=device, seed=cfg.seed,
+                                    env_id_offset=cfg.env_id_offset, rng_mode="tape" if cfg.rng_mode == 1 else "philox",
+                                    max_steps=cfg.max_steps, max_path_length=cfg.max_path_length, channel=ch)
+        b = self.batch
+        self.B, self.N, self.M, self.S, self.d = b.B, b.N, b.M, b.S, b.d
+        self.n_empty_cells = b.n_empty_cells
+
+    def _refresh(self):
+        b = self.batch
+        b.check_status()
+        st = b.get_state()
+        self.agent_pos, self.prey_pos, self.prey_alive = st["agent_pos"], st["prey_pos"], st["prey_alive"]
+        self.visited, self.step_count, self.total_capture = st["visited"], st["step_count"], st["total_capture"]
+        self.success, self.ge_state, self.rng_step = st["success"], st["ge_state"], st["rng_step"]
+        self.obs = b.obs.cpu().numpy()
+        self.reward = b.reward64.cpu().numpy()
+        self.reward32 = b.reward.cpu().numpy()
+        self.done = b.done.cpu().numpy()
+        self.details = b.details.cpu().numpy()
+        self.dist_adj = b.dist_adj.cpu().numpy()
+        self.channels = b.channels.cpu().numpy()
+        self.prey_alive_info = b.prey_alive.cpu().numpy()[:, :self.M]
+
+    def reset(self, **tape):
+        self.batch.reset_all(tape={k: v for k, v in tape.items() if v is not None} or None)
+        self._refresh()
+        return self.obs
+
+    def step(self, actions, n_threads=1, **tape):
+        a = torch.as_tensor(np.ascontiguousarray(actions, dtype=np.int32)).to(self.batch.device)
+        self.batch.step_device(a, tape={k: v for k, v in tape.items() if v is not None} or None)
+        self._refresh()
+        return self.obs, self.reward, self.done
+
+    def visited_dense(self):
+        cols = np.arange(self.S, dtype=np.uint32)
+        return ((self.visited[:, :, None] >> cols[None, None, :]) & 1).astype(np.uint8)

@@ -1,0 +1,77 @@
+"""CPU-side checks of the boundary: the C-ABI library loads and exports every symbol that
+include/commarl.h declares (no compute calls without a GPU), and the product package never
+imports the oracle."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "commarl.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(cm_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    import ctypes
+    from com_marl_amd import _lib
+    lib = _lib.lib()
+    names = declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"libcommarl_hip.so does not export {n}"
+    assert set(names) == set(_lib.EXPORTED), "ctypes binding and header disagree"
+    assert lib.cm_abi_version() == 1
+    assert isinstance(lib.cm_last_error(), (bytes, type(None)))
+
+
+def test_struct_layouts_match_header_sizes():
+    import ctypes as C
+    from com_marl_amd import _lib
+    assert C.sizeof(_lib.EnvCfg) == 16 * 4 + 4 * 4 + 7 * 8 + 8
+    assert C.sizeof(_lib.RngTape) == 5 * 8
+    assert C.sizeof(_lib.StepOut) == 9 * 8
+    assert C.sizeof(_lib.EnvState) == 9 * 8
+    assert C.sizeof(_lib.PolicyWeights) == 10 * 4 + 15 * 8
+    assert C.sizeof(_lib.CriticWeights) == 6 * 4 + 11 * 8
+
+
+def test_argument_errors_without_gpu():
+    """Pure argument validation paths return error codes + text, no exception crosses the ABI."""
+    import ctypes as C
+    from com_marl_amd import _lib
+    lib = _lib.lib()
+    h = C.c_void_p()
+    assert lib.cm_env_create(None, C.byref(h)) == -1
+    assert b"null" in lib.cm_last_error()
+    cfg = _lib.EnvCfg()
+    cfg.scenario = 7
+    assert lib.cm_env_create(C.byref(cfg), C.byref(h)) == -1
+    assert lib.cm_policy_forward(None, 4, None, None, None, None, 0, 0, 0, 0, None, None, None, None) == -1
+    assert lib.cm_gae(0, 0, None, None, None, 0.99, 0.97, 0, 1e-8, None, None) == -1
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: no product file may import, load or link it."""
+    pkg = os.path.join(ROOT, "com-marl_amd")
+    bad = re.compile(r"^\s*(from|import)\s+oracle\b|libcm_oracle|cm_oracle\.h|cmo_[a-z_]+\(", re.M)
+    n = 0
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
+                n += 1
+                assert not bad.search(open(os.path.join(dirpath, f)).read()), f"{f} touches the oracle"
+    assert n >= 8
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from com_marl_amd import envs, CommarlError
+    with pytest.raises(CommarlError):
+        envs.GridEnvBatch("pp", dict(n_agents=4, n_preys=4, grid_size=10, Rsen=1, n_gcn_layers=2, trpl=0,
+                                     max_env_steps=200), 2, device="cpu")

@@ -1,0 +1,139 @@
+"""GPU parity of the HIP env step (through the C ABI) against (a) the reference's golden
+vectors in RNG-tape mode - bit-exact integer state, exact f32 obs / f64 reward - and (b) the
+CPU oracle in production Philox mode at BASELINE sizes."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.test_oracle_golden import ENV_FIXTURES, replay
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need the MI355X")
+    from tests import hip_adapters
+    return hip_adapters
+
+
+@pytest.mark.parametrize("path", ENV_FIXTURES, ids=[os.path.basename(p)[4:-4] for p in ENV_FIXTURES])
+def test_env_hip_matches_reference_golden(path, hip):
+    replay(path, hip.HipEnv)
+
+
+def _lockstep(cfg_kwargs, steps, hip, seed=1234, check_every=1):
+    """Same Philox stream, same random actions through oracle and HIP; compare everything."""
+    cfg_o = O.make_cfg(**cfg_kwargs, rng_mode=O.RNG_PHILOX, seed=seed)
+    cfg_h = O.make_cfg(**cfg_kwargs, rng_mode=O.RNG_PHILOX, seed=seed)
+    eo, eh = O.OracleEnv(cfg_o), hip.HipEnv(cfg_h)
+    eo.reset()
+    eh.reset()
+    rng = np.random.RandomState(seed)
+    B, N = eo.B, eo.N
+    n_done = 0
+    for t in range(steps):
+        a = rng.randint(0, 5, size=(B, N)).astype(np.int32)
+        eo.step(a, n_threads=8)
+        eh.step(a)
+        if t % check_every and t != steps - 1:
+            continue
+        w = f"step {t}"
+        np.testing.assert_array_equal(eh.done, eo.done, err_msg=w)
+        np.testing.assert_array_equal(eh.reward, eo.reward, err_msg=w)
+        np.testing.assert_array_equal(eh.reward32, eo.reward.astype(np.float32), err_msg=w)
+        np.testing.assert_array_equal(eh.details, eo.details, err_msg=w)
+        np.testing.assert_array_equal(eh.agent_pos, eo.agent_pos, err_msg=w)
+        np.testing.assert_array_equal(eh.step_count, eo.step_count, err_msg=w)
+        np.testing.assert_array_equal(eh.success, eo.success, err_msg=w)
+        np.testing.assert_array_equal(eh.rng_step, eo.rng_step, err_msg=w)
+        if eo.M:
+            alive = eo.prey_alive.astype(bool)
+            np.testing.assert_array_equal(eh.prey_alive.astype(bool), alive, err_msg=w)
+            np.testing.assert_array_equal(eh.prey_pos[alive], eo.prey_pos[alive], err_msg=w)
+            np.testing.assert_array_equal(eh.prey_alive_info, eo.prey_alive_info[:, :eo.M], err_msg=w)
+        else:
+            np.testing.assert_array_equal(eh.visited, eo.visited, err_msg=w)
+            np.testing.assert_array_equal(eh.total_capture, eo.total_capture, err_msg=w)
+        np.testing.assert_array_equal(eh.obs, eo.obs, err_msg=w)
+        np.testing.assert_array_equal(eh.dist_adj, eo.dist_adj, err_msg=w)
+        np.testing.assert_array_equal(eh.channels, eo.channels, err_msg=w)
+        if cfg_o.channel == 3:
+            np.testing.assert_array_equal(eh.ge_state, eo.ge_state, err_msg=w)
+        n_done += int(eo.done.sum())
+    return n_done
+
+
+def test_philox_pp_config2_4096_envs(hip):
+    """BASELINE config 2: PP map10 sen1 den.04 cap2, 4096 envs, > 1 full episode incl. resets."""
+    n = _lockstep(dict(scenario="pp", n_envs=4096, n_agents=4, n_preys=4, grid=10, rsen=1, load=2, max_steps=200),
+                  steps=230, hip=hip, check_every=10)
+    assert n >= 4096
+
+
+def test_philox_co_config3_2048_envs(hip):
+    n = _lockstep(dict(scenario="co", n_envs=2048, n_agents=24, grid=20, rsen=2, max_steps=400, max_path_length=40),
+                  steps=90, hip=hip, check_every=9)
+    assert n >= 2048
+
+
+def test_philox_pp_config4_map30_cap4(hip):
+    n = _lockstep(dict(scenario="pp", n_envs=256, n_agents=72, n_preys=72, grid=30, rsen=2, load=4, max_steps=25),
+                  steps=60, hip=hip, check_every=6)
+    assert n >= 256
+
+
+def test_philox_co_config5_map30_iid(hip):
+    n = _lockstep(dict(scenario="co", n_envs=128, n_agents=54, grid=30, rsen=2, max_steps=400, max_path_length=15,
+                       channel="IID", ploss=0.3), steps=35, hip=hip, check_every=5)
+    assert n >= 128
+
+
+def test_philox_co_map30_ge(hip):
+    n = _lockstep(dict(scenario="co", n_envs=64, n_agents=54, grid=30, rsen=2, max_steps=400, max_path_length=12,
+                       channel="GE"), steps=30, hip=hip, check_every=3)
+    assert n >= 64
+
+
+def test_philox_pp_load3_and_fl(hip):
+    _lockstep(dict(scenario="pp", n_envs=512, n_agents=8, n_preys=8, grid=10, rsen=1, load=3, max_steps=30,
+                   channel="FL", ploss=1.0), steps=70, hip=hip, check_every=7)
+
+
+def test_odd_agent_counts_and_hard_obstacles(hip):
+    _lockstep(dict(scenario="co", n_envs=100, n_agents=3, grid=10, rsen=1, max_steps=400, max_path_length=20,
+                   channel="IID", ploss=0.5, obst="Hard", add_clock=1), steps=45, hip=hip, check_every=5)
+    _lockstep(dict(scenario="pp", n_envs=100, n_agents=5, n_preys=7, grid=12, rsen=2, load=2, max_steps=20, rcom=3,
+                   channel="GE"), steps=45, hip=hip, check_every=5)
+
+
+def test_bad_action_is_reported(hip):
+    cfg = O.make_cfg("pp", 4, 4, 10, 1, n_preys=4, rng_mode=O.RNG_PHILOX)
+    e = hip.HipEnv(cfg)
+    e.reset()
+    a = np.zeros((4, 4), np.int32)
+    a[2, 1] = 7
+    from com_marl_amd import CommarlError
+    with pytest.raises(CommarlError):
+        e.step(a)
+
+
+def test_tape_exhaustion_is_reported(hip):
+    cfg = O.make_cfg("pp", 2, 4, 10, 1, n_preys=4, rng_mode=O.RNG_TAPE)
+    e = hip.HipEnv(cfg)
+    from com_marl_amd import CommarlError
+    with pytest.raises(CommarlError):
+        e.reset(spawn=np.full((2, 3, 2), -1, np.int32))
+
+
+def test_unsupported_config_is_refused(hip):
+    from com_marl_amd import CommarlError
+    with pytest.raises(CommarlError):
+        hip.HipEnv(O.make_cfg("pp", 2, 4, 10, 1, n_preys=4, load=5))
+    with pytest.raises(CommarlError):
+        hip.HipEnv(O.make_cfg("pp", 2, 4, 40, 1, n_preys=4))     # grid side > 32
