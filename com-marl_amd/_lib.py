@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libcommarl_hip.so")
+# COMMARL_LIB selects another build of the same ABI (e.g. the -DCM_BOUNDS checked build)
+LIB_PATH = os.environ.get("COMMARL_LIB") or os.path.join(HERE, "libcommarl_hip.so")
 
 CM_PP, CM_CO = 0, 1
 CHANNELS = {"FC": 0, "FL": 1, "IID": 2, "GE": 3}

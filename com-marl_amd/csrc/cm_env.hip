@@ -36,37 +36,67 @@ constexpr int WAVE = 64;
 __device__ __forceinline__ int dr_of(int a) { return a == 0 ? 1 : (a == 2 ? -1 : 0); }   // predator_prey.py:244-253
 __device__ __forceinline__ int dc_of(int a) { return a == 1 ? -1 : (a == 3 ? 1 : 0); }
 __device__ __forceinline__ bool in_grid(int r, int c, int S) { return (unsigned)r < (unsigned)S && (unsigned)c < (unsigned)S; }
-__device__ __forceinline__ int cell(const uint8_t *g, int r, int c, int S) { return in_grid(r, c, S) ? (int)g[r * S + c] : -1; }
+// (cell / count_adj are defined after the LDS accessors)
 // _neighbour_agents / _neighbour_preys count (predator_prey.py:309-351): D,U,R,L, each bounds-checked
-__device__ __forceinline__ int count_adj(const uint8_t *g, int r, int c, int S, int kind) {
-    return (cell(g, r + 1, c, S) == kind) + (cell(g, r - 1, c, S) == kind) + (cell(g, r, c + 1, S) == kind) +
-           (cell(g, r, c - 1, S) == kind);
-}
 __device__ __forceinline__ void raise(const EnvDev &p, int code) { atomicCAS(p.status, 0, code); }
 
-struct Lds {
-    uint8_t *g;        // [S*S] occupancy tile
-    int16_t *ar, *ac;  // [N]
-    int16_t *pr, *pc;  // [M]
-    uint8_t *act;      // [N]
-    uint8_t *alive;    // [M]
-    uint8_t *pcnt;     // [M] predator count around prey j
-    uint8_t *pmv;      // [M] chosen prey move | 8 = tape ran out
-    uint32_t *vis;     // [S]
+// Dynamic LDS of the single-wave workgroup.  Everything is addressed as smem + integer offset so that
+// the compiler keeps the accesses in the LDS address space (ds_read/ds_write), never as flat pointers.
+extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+struct Lds {           // byte offsets into smem
+    int g;             // [S*S] u8 occupancy tile
+    int ar, ac;        // [N] i16
+    int pr, pc;        // [M] i16
+    int act;           // [N] u8
+    int alive;         // [M] u8
+    int pcnt;          // [M] u8 predator count around prey j
+    int pmv;           // [M] u8 chosen prey move | 8 = tape ran out
+    int vis;           // [S] u32
+    int nS2, nN, nM, nS;
+    int32_t *status;
 };
 
-__host__ __device__ inline size_t lds_layout(int S, int N, int M, Lds *l, unsigned char *base) {
-    size_t off = 0;
-    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 15) & ~size_t(15); return o; };
-    size_t o_g = take((size_t)S * S), o_ar = take(2 * (size_t)N), o_ac = take(2 * (size_t)N), o_pr = take(2 * (size_t)M),
-           o_pc = take(2 * (size_t)M), o_act = take(N), o_al = take(M), o_pcnt = take(M), o_pmv = take(M),
-           o_vis = take(4 * (size_t)S);
+__host__ __device__ inline int lds_take(int &off, int bytes) { const int o = off; off += (bytes + 15) & ~15; return o; }
+__host__ __device__ inline size_t lds_layout(int S, int N, int M, Lds *l) {
+    int off = 0;
+    const int g = lds_take(off, S * S), ar = lds_take(off, 2 * N), ac = lds_take(off, 2 * N), pr = lds_take(off, 2 * M),
+              pc = lds_take(off, 2 * M), act = lds_take(off, N), alive = lds_take(off, M), pcnt = lds_take(off, M),
+              pmv = lds_take(off, M), vis = lds_take(off, 4 * S);
     if (l) {
-        l->g = base + o_g; l->ar = (int16_t *)(base + o_ar); l->ac = (int16_t *)(base + o_ac);
-        l->pr = (int16_t *)(base + o_pr); l->pc = (int16_t *)(base + o_pc); l->act = base + o_act;
-        l->alive = base + o_al; l->pcnt = base + o_pcnt; l->pmv = base + o_pmv; l->vis = (uint32_t *)(base + o_vis);
+        l->g = g; l->ar = ar; l->ac = ac; l->pr = pr; l->pc = pc; l->act = act; l->alive = alive; l->pcnt = pcnt;
+        l->pmv = pmv; l->vis = vis; l->nS2 = S * S; l->nN = N; l->nM = M; l->nS = S;
     }
-    return off;
+    return (size_t)off;
+}
+
+// -DCM_BOUNDS builds a checked variant: an out-of-range LDS index raises status -100-site instead of
+// silently reading 0 (LDS out-of-range reads are not faults), used to hunt indexing bugs on the GPU.
+#ifdef CM_BOUNDS
+__device__ __forceinline__ int chk(const Lds &l, int i, int n, int site) {
+    if ((unsigned)i < (unsigned)n) return i;
+    atomicCAS(l.status, 0, -100 - site);
+    return 0;
+}
+#else
+__device__ __forceinline__ int chk(const Lds &, int i, int, int) { return i; }
+#endif
+__device__ __forceinline__ uint8_t &Gc(const Lds &l, int i) { return smem[l.g + chk(l, i, l.nS2, 1)]; }
+__device__ __forceinline__ int16_t &AR(const Lds &l, int i) { return reinterpret_cast<int16_t *>(smem + l.ar)[chk(l, i, l.nN, 2)]; }
+__device__ __forceinline__ int16_t &AC(const Lds &l, int i) { return reinterpret_cast<int16_t *>(smem + l.ac)[chk(l, i, l.nN, 3)]; }
+__device__ __forceinline__ int16_t &PR(const Lds &l, int i) { return reinterpret_cast<int16_t *>(smem + l.pr)[chk(l, i, l.nM, 4)]; }
+__device__ __forceinline__ int16_t &PC(const Lds &l, int i) { return reinterpret_cast<int16_t *>(smem + l.pc)[chk(l, i, l.nM, 5)]; }
+__device__ __forceinline__ uint8_t &ACT(const Lds &l, int i) { return smem[l.act + chk(l, i, l.nN, 6)]; }
+__device__ __forceinline__ uint8_t &ALV(const Lds &l, int i) { return smem[l.alive + chk(l, i, l.nM, 7)]; }
+__device__ __forceinline__ uint8_t &PCNT(const Lds &l, int i) { return smem[l.pcnt + chk(l, i, l.nM, 8)]; }
+__device__ __forceinline__ uint8_t &PMV(const Lds &l, int i) { return smem[l.pmv + chk(l, i, l.nM, 9)]; }
+__device__ __forceinline__ uint32_t &VIS(const Lds &l, int i) { return reinterpret_cast<uint32_t *>(smem + l.vis)[chk(l, i, l.nS, 10)]; }
+
+__device__ __forceinline__ int cell(const Lds &l, int r, int c, int S) { return in_grid(r, c, S) ? (int)Gc(l, r * S + c) : -1; }
+// _neighbour_agents / _neighbour_preys count (predator_prey.py:309-351): D,U,R,L, each bounds-checked
+__device__ __forceinline__ int count_adj(const Lds &l, int r, int c, int S, int kind) {
+    return (cell(l, r + 1, c, S) == kind) + (cell(l, r - 1, c, S) == kind) + (cell(l, r, c + 1, S) == kind) +
+           (cell(l, r, c - 1, S) == kind);
 }
 
 struct Rng {
@@ -80,9 +110,12 @@ __device__ __forceinline__ void uniform4(const Rng &rng, uint32_t site, uint32_t
     const u32x4 a = rng.at(site, q);
     if (o == 0) { u[0] = unit_f32(a.x); u[1] = unit_f32(a.y); u[2] = unit_f32(a.z); u[3] = unit_f32(a.w); return; }
     const u32x4 b = rng.at(site, q + 1);
-    const uint32_t w[8] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w };
-#pragma unroll
-    for (int i = 0; i < 4; ++i) u[i] = unit_f32(w[o + i]);
+    // window of 4 words starting at component o of (a, b), without a dynamically indexed array
+    const uint32_t w0 = o == 1 ? a.y : (o == 2 ? a.z : a.w);
+    const uint32_t w1 = o == 1 ? a.z : (o == 2 ? a.w : b.x);
+    const uint32_t w2 = o == 1 ? a.w : (o == 2 ? b.x : b.y);
+    const uint32_t w3 = o == 1 ? b.x : (o == 2 ? b.y : b.z);
+    u[0] = unit_f32(w0); u[1] = unit_f32(w1); u[2] = unit_f32(w2); u[3] = unit_f32(w3);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -90,11 +123,11 @@ __device__ __forceinline__ void uniform4(const Rng &rng, uint32_t site, uint32_t
 // Wave-uniform loop: every lane evaluates the same candidate, lane 0 commits it.
 // ---------------------------------------------------------------------------------------
 template <int SCEN>
-__device__ void do_reset(const EnvDev &p, const Lds &l, const Rng &rng, const cm_rng_tape &tape, int b, int lane) {
+__device__ __forceinline__ void do_reset(const EnvDev &p, const Lds l, const Rng rng, const cm_rng_tape &tape, int b, int lane) {
     const int S = p.S, N = p.N, M = p.M;
     // fresh tile
-    for (int k = lane; k < S * S; k += WAVE) l.g[k] = (SCEN == CM_CO) ? p.base_grid[k] : (uint8_t)C_EMPTY;
-    if (SCEN == CM_CO) for (int r = lane; r < S; r += WAVE) l.vis[r] = 0u;
+    for (int k = lane; k < S * S; k += WAVE) Gc(l, k) = (SCEN == CM_CO) ? p.base_grid[k] : (uint8_t)C_EMPTY;
+    if (SCEN == CM_CO) for (int r = lane; r < S; r += WAVE) VIS(l, r) = 0u;
     __syncthreads();
     const int lo = (SCEN == CM_CO) ? 1 : 0;                              // randint(1, m) vs randint(0, G-1)
     int cursor = 0;
@@ -116,13 +149,13 @@ __device__ void do_reset(const EnvDev &p, const Lds &l, const Rng &rng, const cm
                 c = lo + (int)__umulhi(x.y, sp);
             }
             ++cursor;
-            bool ok = in_grid(r, c, S) && l.g[r * S + c] == C_EMPTY;          // _is_cell_vacant
-            if (ok && is_prey) ok = count_adj(l.g, r, c, S, C_AGENT) == 0;    // predator_prey.py:166
+            bool ok = in_grid(r, c, S) && Gc(l, r * S + c) == C_EMPTY;          // _is_cell_vacant
+            if (ok && is_prey) ok = count_adj(l, r, c, S, C_AGENT) == 0;    // predator_prey.py:166
             if (ok) {
                 if (lane == 0) {
-                    if (!is_prey) { l.ar[e] = (int16_t)r; l.ac[e] = (int16_t)c; l.g[r * S + c] = C_AGENT;
-                                    if (SCEN == CM_CO) l.vis[r] |= (1u << c); }      // coverage.py:187
-                    else { l.pr[e - N] = (int16_t)r; l.pc[e - N] = (int16_t)c; l.g[r * S + c] = C_PREY; }
+                    if (!is_prey) { AR(l, e) = (int16_t)r; AC(l, e) = (int16_t)c; Gc(l, r * S + c) = C_AGENT;
+                                    if (SCEN == CM_CO) VIS(l, r) |= (1u << c); }      // coverage.py:187
+                    else { PR(l, e - N) = (int16_t)r; PC(l, e - N) = (int16_t)c; Gc(l, r * S + c) = C_PREY; }
                 }
                 __syncthreads();
                 break;
@@ -130,7 +163,7 @@ __device__ void do_reset(const EnvDev &p, const Lds &l, const Rng &rng, const cm
         }
     }
     if (fail && lane == 0) raise(p, CM_ERR_TAPE);
-    for (int j = lane; j < M; j += WAVE) l.alive[j] = 1;
+    for (int j = lane; j < M; j += WAVE) ALV(l, j) = 1;
     __syncthreads();
 }
 
@@ -138,7 +171,7 @@ __device__ void do_reset(const EnvDev &p, const Lds &l, const Rng &rng, const cm
 // emission: obs + dist_adj + channels + state write-back
 // ---------------------------------------------------------------------------------------
 template <int SCEN>
-__device__ void emit(const EnvDev &p, const Lds &l, const Rng &rng, const cm_rng_tape &tape, const cm_step_out &out,
+__device__ __forceinline__ void emit(const EnvDev &p, const Lds l, const Rng rng, const cm_rng_tape &tape, const cm_step_out &out,
                      int b, int lane, int step_count, int slot) {
     const int S = p.S, N = p.N, M = p.M, R = p.R, W = p.W, d = p.d, WW = W * W;
     // ---- observations [N*d], lanes stride the flattened row -> coalesced 256-B stores ----
@@ -147,12 +180,12 @@ __device__ void emit(const EnvDev &p, const Lds &l, const Rng &rng, const cm_rng
         const int total = N * d;
         for (int k = lane; k < total; k += WAVE) {
             const int i = k / d, f = k - i * d;
-            const int r0 = l.ar[i], c0 = l.ac[i];
+            const int r0 = AR(l, i), c0 = AC(l, i);
             float v;
             if (SCEN == CM_PP) {
                 if (f < 2 * WW) {                                   // get_neighbors (predator_prey.py:173-181)
                     const int chn = f >= WW, w = f - chn * WW, wr = w / W, wc = w - wr * W;
-                    v = (cell(l.g, r0 - R + wr, c0 - R + wc, S) == (chn ? C_PREY : C_AGENT)) ? 1.0f : 0.0f;
+                    v = (cell(l, r0 - R + wr, c0 - R + wc, S) == (chn ? C_PREY : C_AGENT)) ? 1.0f : 0.0f;
                 } else if (f == 2 * WW) v = p.lut_row[r0];          // row / G          (:195)
                 else if (f == 2 * WW + 1) v = p.lut_col[c0];        // col / (G-1)      (:195)
                 else v = p.lut_step[step_count];                    // step / Tmax      (:196)
@@ -161,9 +194,9 @@ __device__ void emit(const EnvDev &p, const Lds &l, const Rng &rng, const cm_rng
                     const int chn = f / WW, w = f - chn * WW, wr = w / W, wc = w - wr * W;
                     const int rr = r0 - R + wr, cc = c0 - R + wc;
                     const bool in = in_grid(rr, cc, S);
-                    if (chn == 0) v = (!in || l.g[rr * S + cc] == C_WALL) ? 1.0f : 0.0f;
-                    else if (chn == 1) v = (in && l.g[rr * S + cc] == C_AGENT) ? 1.0f : 0.0f;
-                    else v = (in && ((l.vis[rr] >> cc) & 1u)) ? 1.0f : 0.0f;
+                    if (chn == 0) v = (!in || Gc(l, rr * S + cc) == C_WALL) ? 1.0f : 0.0f;
+                    else if (chn == 1) v = (in && Gc(l, rr * S + cc) == C_AGENT) ? 1.0f : 0.0f;
+                    else v = (in && ((VIS(l, rr) >> cc) & 1u)) ? 1.0f : 0.0f;
                 } else if (f == 3 * WW) v = p.lut_row[r0];          // round(row/(S-1), 2) (:206)
                 else if (f == 3 * WW + 1) v = p.lut_col[c0];
                 else v = p.lut_step[step_count];
@@ -176,7 +209,7 @@ __device__ void emit(const EnvDev &p, const Lds &l, const Rng &rng, const cm_rng
         float *a = out.dist_adj + (size_t)b * N * N;
         for (int k = lane; k < N * N; k += WAVE) {
             const int i = k / N, j = k - i * N;
-            const int dr = l.ar[i] - l.ar[j], dc = l.ac[i] - l.ac[j];
+            const int dr = AR(l, i) - AR(l, j), dc = AC(l, i) - AC(l, j);
             a[k] = (dr * dr + dc * dc <= p.rc2) ? 1.0f : 0.0f;
         }
     }
@@ -241,14 +274,14 @@ __device__ void emit(const EnvDev &p, const Lds &l, const Rng &rng, const cm_rng
         }
     }
     // ---- state write-back ----
-    for (int i = lane; i < N; i += WAVE) p.agent_pos[(size_t)b * N + i] = make_int2(l.ar[i], l.ac[i]);
+    for (int i = lane; i < N; i += WAVE) p.agent_pos[(size_t)b * N + i] = make_int2(AR(l, i), AC(l, i));
     if (SCEN == CM_PP) {
         for (int j = lane; j < M; j += WAVE) {
-            p.prey_pos[(size_t)b * M + j] = make_int2(l.pr[j], l.pc[j]);
-            p.alive[(size_t)b * M + j] = l.alive[j];
+            p.prey_pos[(size_t)b * M + j] = make_int2(PR(l, j), PC(l, j));
+            p.alive[(size_t)b * M + j] = ALV(l, j);
         }
     } else {
-        for (int r = lane; r < S; r += WAVE) p.visited[(size_t)b * S + r] = l.vis[r];
+        for (int r = lane; r < S; r += WAVE) p.visited[(size_t)b * S + r] = VIS(l, r);
     }
 }
 
@@ -258,9 +291,9 @@ __device__ void emit(const EnvDev &p, const Lds &l, const Rng &rng, const cm_rng
 template <int SCEN>
 __global__ __launch_bounds__(WAVE) void env_kernel(EnvDev p, const int32_t *__restrict__ actions, cm_rng_tape tape,
                                                   cm_step_out out, int reset_only) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Lds l;
-    lds_layout(p.S, p.N, p.M, &l, smem);
+    lds_layout(p.S, p.N, p.M, &l);
+    l.status = p.status;
     const int b = blockIdx.x, lane = threadIdx.x;
     const int S = p.S, N = p.N, M = p.M;
     Rng rng{ (uint32_t)(p.env_id_offset + b), p.rng_step[b], p.key0, p.key1 };
@@ -276,27 +309,27 @@ __global__ __launch_bounds__(WAVE) void env_kernel(EnvDev p, const int32_t *__re
     bool bad_action = false;
     for (int i = lane; i < N; i += WAVE) {
         const int2 q = p.agent_pos[(size_t)b * N + i];
-        l.ar[i] = (int16_t)q.x; l.ac[i] = (int16_t)q.y;
+        AR(l, i) = (int16_t)q.x; AC(l, i) = (int16_t)q.y;
         const int a = actions[(size_t)b * N + i];
         bad_action |= (unsigned)a > 4u;
-        l.act[i] = (uint8_t)(a & 7);
+        ACT(l, i) = (uint8_t)(a & 7);
     }
     if (SCEN == CM_PP)
         for (int j = lane; j < M; j += WAVE) {
             const int2 q = p.prey_pos[(size_t)b * M + j];
-            l.pr[j] = (int16_t)q.x; l.pc[j] = (int16_t)q.y;
-            l.alive[j] = p.alive[(size_t)b * M + j];
+            PR(l, j) = (int16_t)q.x; PC(l, j) = (int16_t)q.y;
+            ALV(l, j) = p.alive[(size_t)b * M + j];
         }
-    for (int k = lane; k < S * S; k += WAVE) l.g[k] = (SCEN == CM_CO) ? p.base_grid[k] : (uint8_t)C_EMPTY;
-    if (SCEN == CM_CO) for (int r = lane; r < S; r += WAVE) l.vis[r] = p.visited[(size_t)b * S + r];
+    for (int k = lane; k < S * S; k += WAVE) Gc(l, k) = (SCEN == CM_CO) ? p.base_grid[k] : (uint8_t)C_EMPTY;
+    if (SCEN == CM_CO) for (int r = lane; r < S; r += WAVE) VIS(l, r) = p.visited[(size_t)b * S + r];
     if (__any(bad_action)) {               // the reference raises (predator_prey.py:255); flag and leave state untouched
         if (lane == 0) raise(p, CM_ERR_ACTION);
         return;
     }
     __syncthreads();
-    for (int i = lane; i < N; i += WAVE) l.g[l.ar[i] * S + l.ac[i]] = C_AGENT;
+    for (int i = lane; i < N; i += WAVE) Gc(l, AR(l, i) * S + AC(l, i)) = C_AGENT;
     if (SCEN == CM_PP)
-        for (int j = lane; j < M; j += WAVE) if (l.alive[j]) l.g[l.pr[j] * S + l.pc[j]] = C_PREY;
+        for (int j = lane; j < M; j += WAVE) if (ALV(l, j)) Gc(l, PR(l, j) * S + PC(l, j)) = C_PREY;
     __syncthreads();
 
     int step_count = p.step_count[b] + 1;
@@ -309,12 +342,12 @@ __global__ __launch_bounds__(WAVE) void env_kernel(EnvDev p, const int32_t *__re
         // ---- agents move in index order (predator_prey.py:497-500, :240-261) : wave-uniform ----
         int moving = 0;
         for (int i = 0; i < N; ++i) {
-            const int a = l.act[i];
+            const int a = ACT(l, i);
             if (a != 4) {
                 ++moving;
-                const int r = l.ar[i], c = l.ac[i], nr = r + dr_of(a), nc = c + dc_of(a);
-                if (in_grid(nr, nc, S) && l.g[nr * S + nc] == C_EMPTY) {
-                    if (lane == 0) { l.g[r * S + c] = C_EMPTY; l.g[nr * S + nc] = C_AGENT; l.ar[i] = (int16_t)nr; l.ac[i] = (int16_t)nc; }
+                const int r = AR(l, i), c = AC(l, i), nr = r + dr_of(a), nc = c + dc_of(a);
+                if (in_grid(nr, nc, S) && Gc(l, nr * S + nc) == C_EMPTY) {
+                    if (lane == 0) { Gc(l, r * S + c) = C_EMPTY; Gc(l, nr * S + nc) = C_AGENT; AR(l, i) = (int16_t)nr; AC(l, i) = (int16_t)nc; }
                     __syncthreads();
                 }
             }
@@ -323,9 +356,9 @@ __global__ __launch_bounds__(WAVE) void env_kernel(EnvDev p, const int32_t *__re
         // ---- per-prey work that only depends on the (now static) agent layer: one lane per prey ----
         for (int j = lane; j < M; j += WAVE) {
             int cnt = 0, mv = 4;
-            if (l.alive[j]) {
-                const int r = l.pr[j], c = l.pc[j];
-                cnt = count_adj(l.g, r, c, S, C_AGENT);
+            if (ALV(l, j)) {
+                const int r = PR(l, j), c = PC(l, j);
+                cnt = count_adj(l, r, c, S, C_AGENT);
                 // prey_random_move (:396-407): first of <=5 draws whose target has no predator neighbour
                 const bool captured_now = (p.load == 2) && cnt >= 1 && p.load <= cnt;
                 if (!captured_now) {
@@ -340,17 +373,17 @@ __global__ __launch_bounds__(WAVE) void env_kernel(EnvDev p, const int32_t *__re
                             if ((t & 3) == 0) x = rng.at(SITE_PREY, (uint32_t)(2 * j + (t >> 2)));
                             m = prey_move_from_u32(pick(x, t & 3));
                         }
-                        if (count_adj(l.g, r + dr_of(m), c + dc_of(m), S, C_AGENT) == 0) { mv = m; found = true; }
+                        if (count_adj(l, r + dr_of(m), c + dc_of(m), S, C_AGENT) == 0) { mv = m; found = true; }
                     }
                 }
             }
-            l.pcnt[j] = (uint8_t)cnt; l.pmv[j] = (uint8_t)mv;
+            PCNT(l, j) = (uint8_t)cnt; PMV(l, j) = (uint8_t)mv;
         }
         // prey_watching (:419-423): agents 4-adjacent to a live prey (prey layer still at start-of-phase positions)
         int wsum = 0;
         for (int i0 = 0; i0 < N; i0 += WAVE) {
             const int i = i0 + lane;
-            const bool w = i < N && count_adj(l.g, l.ar[i], l.ac[i], S, C_PREY) > 0;
+            const bool w = i < N && count_adj(l, AR(l, i), AC(l, i), S, C_PREY) > 0;
             wsum += __popcll(__ballot(w));
         }
         __syncthreads();
@@ -358,29 +391,29 @@ __global__ __launch_bounds__(WAVE) void env_kernel(EnvDev p, const int32_t *__re
         int capture = 0, penalty = 0;
         bool tape_short = false;
         for (int j = 0; j < M; ++j) {
-            if (!l.alive[j]) continue;
-            const int r = l.pr[j], c = l.pc[j], cnt = l.pcnt[j], mvb = l.pmv[j];
+            if (!ALV(l, j)) continue;
+            const int r = PR(l, j), c = PC(l, j), cnt = PCNT(l, j), mvb = PMV(l, j);
             bool captured = false;
             if (cnt >= 1) {
                 int need = p.load;
                 if (p.load != 2) {                                       // reward_individual :467-470
                     const bool on_r = (r == 0 || r == S - 1), on_c = (c == 0 || c == S - 1);
                     const int adj = (on_r && on_c) ? 2 : ((on_r || on_c) ? 3 : p.load);   // __create_edges :123-144
-                    const int avail = adj - count_adj(l.g, r, c, S, C_PREY);
+                    const int avail = adj - count_adj(l, r, c, S, C_PREY);
                     need = p.load < avail ? p.load : avail;
                 }
                 if (need <= cnt) { captured = true; ++capture; } else ++penalty;
             }
             if (captured) {
-                if (lane == 0) { l.alive[j] = 0; l.g[r * S + c] = C_EMPTY; }      // :301
+                if (lane == 0) { ALV(l, j) = 0; Gc(l, r * S + c) = C_EMPTY; }      // :301
                 __syncthreads();
             } else {
                 if (mvb & 8) tape_short = true;
                 const int mv = mvb & 7;
                 if (mv != 4) {
                     const int nr = r + dr_of(mv), nc = c + dc_of(mv);
-                    if (in_grid(nr, nc, S) && l.g[nr * S + nc] == C_EMPTY) {
-                        if (lane == 0) { l.g[r * S + c] = C_EMPTY; l.g[nr * S + nc] = C_PREY; l.pr[j] = (int16_t)nr; l.pc[j] = (int16_t)nc; }
+                    if (in_grid(nr, nc, S) && Gc(l, nr * S + nc) == C_EMPTY) {
+                        if (lane == 0) { Gc(l, r * S + c) = C_EMPTY; Gc(l, nr * S + nc) = C_PREY; PR(l, j) = (int16_t)nr; PC(l, j) = (int16_t)nc; }
                         __syncthreads();
                     }
                 }
@@ -393,24 +426,24 @@ __global__ __launch_bounds__(WAVE) void env_kernel(EnvDev p, const int32_t *__re
         if (p.load == 2) reward = reward + p.penalty * (double)penalty;
         det[0] = capture; det[1] = moving; det[2] = penalty; det[4] = wsum;
         bool any_alive = false;
-        for (int j0 = 0; j0 < M; j0 += WAVE) any_alive |= __any(j0 + lane < M && l.alive[j0 + lane]);
-        if (out.prey_alive) for (int j = lane; j < M; j += WAVE) out.prey_alive[(size_t)b * M + j] = l.alive[j];
+        for (int j0 = 0; j0 < M; j0 += WAVE) any_alive |= __any(j0 + lane < M && ALV(l, j0 + lane));
+        if (out.prey_alive) for (int j = lane; j < M; j += WAVE) out.prey_alive[(size_t)b * M + j] = ALV(l, j);
         done = (step_count >= p.max_steps) || !any_alive;               // :511-517
         if (done) succ = any_alive ? 0 : 1;
     } else {
         // ---- Coverage.step (:319-378): sequential agents against tile + visited bitmap ----
         int cap = 0, mov = 0, pen = 0, lazy = 0, rev = 0;
         for (int i = 0; i < N; ++i) {
-            const int a = l.act[i];
+            const int a = ACT(l, i);
             if (a == 4) { ++lazy; continue; }
             ++mov;
-            const int r = l.ar[i], c = l.ac[i], nr = r + dr_of(a), nc = c + dc_of(a);
-            if (in_grid(nr, nc, S) && l.g[nr * S + nc] == C_EMPTY) {
-                const bool seen = (l.vis[nr] >> nc) & 1u;
+            const int r = AR(l, i), c = AC(l, i), nr = r + dr_of(a), nc = c + dc_of(a);
+            if (in_grid(nr, nc, S) && Gc(l, nr * S + nc) == C_EMPTY) {
+                const bool seen = (VIS(l, nr) >> nc) & 1u;
                 if (seen) ++rev; else ++cap;
                 if (lane == 0) {
-                    l.vis[nr] |= (1u << nc);
-                    l.g[r * S + c] = C_EMPTY; l.g[nr * S + nc] = C_AGENT; l.ar[i] = (int16_t)nr; l.ac[i] = (int16_t)nc;
+                    VIS(l, nr) |= (1u << nc);
+                    Gc(l, r * S + c) = C_EMPTY; Gc(l, nr * S + nc) = C_AGENT; AR(l, i) = (int16_t)nr; AC(l, i) = (int16_t)nc;
                 }
                 __syncthreads();
             } else ++pen;
@@ -571,7 +604,7 @@ extern "C" int cm_env_create(const cm_env_cfg *cfg, cm_env_t *out) {
     hipMemcpy(base + o_lc, lut_col.data(), S * 4, hipMemcpyHostToDevice);
     hipMemcpy(base + o_ls, lut_step.data(), (c.max_steps + 1) * 4, hipMemcpyHostToDevice);
     if (c.channel == CM_CH_GE) hipMemset(base + o_ge, 1, B * N * N);
-    h->lds_bytes = lds_layout(S, c.n_agents, M ? M : 1, nullptr, nullptr);
+    h->lds_bytes = lds_layout(S, c.n_agents, M ? M : 1, nullptr);
     e = hipDeviceSynchronize();
     if (e != hipSuccess) { hipFree(h->arena); delete h; return hip_fail(e, "cm_env_create sync"); }
     *out = h;

@@ -41,6 +41,7 @@ def _lockstep(cfg_kwargs, steps, hip, seed=1234, check_every=1):
         a = rng.randint(0, 5, size=(B, N)).astype(np.int32)
         eo.step(a, n_threads=8)
         eh.step(a)
+        n_done += int(eo.done.sum())
         if t % check_every and t != steps - 1:
             continue
         w = f"step {t}"
@@ -65,7 +66,6 @@ def _lockstep(cfg_kwargs, steps, hip, seed=1234, check_every=1):
         np.testing.assert_array_equal(eh.channels, eo.channels, err_msg=w)
         if cfg_o.channel == 3:
             np.testing.assert_array_equal(eh.ge_state, eo.ge_state, err_msg=w)
-        n_done += int(eo.done.sum())
     return n_done
 
 

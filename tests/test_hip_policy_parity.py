@@ -110,7 +110,9 @@ def test_masked_aggregate_forward_backward(S, N, torch_cuda):
         g_out = torch.autograd.grad((out * w).sum(), (attn, hw, bias))
         g_ref = torch.autograd.grad((ref * w).sum(), (attn, hw, bias))
         for a, b, nm in zip(g_out, g_ref, ("d_attn", "d_hw", "d_bias")):
-            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-4, atol=2e-5, err_msg=f"{nm} hop{hop}")
+            bn = b.cpu().numpy()          # f32 cancellation noise scales with the gradient magnitude
+            np.testing.assert_allclose(a.cpu().numpy(), bn, rtol=2e-4, atol=1e-5 * max(1.0, float(np.abs(bn).max())),
+                                       err_msg=f"{nm} hop{hop}")
     # None masks == all ones
     out = masked_aggregate(attn, None, None, 0, hw, bias)
     ref = _agg_torch(attn, torch.ones_like(adj), torch.ones_like(adj), hw, bias)
@@ -168,7 +170,7 @@ def test_returns_gae_kernels(torch_cuda):
     r[np.arange(T)[None, :] >= lens_np[:, None]] = 0
     b = rng.randn(P, T).astype(np.float32)
     adv = torch.empty(P, T, dtype=torch.float32, device=dev)
-    L.check(L.lib().cm_gae(P, T, L.ptr(torch.as_tensor(r).to(dev)), L.ptr(torch.as_tensor(b).to(dev)),
-                           L.ptr(torch.as_tensor(lens_np).to(dev)), 0.99, 0.97, 1, 1e-8, L.ptr(adv), None))
+    r_d, b_d, l_d = torch.as_tensor(r).to(dev), torch.as_tensor(b).to(dev), torch.as_tensor(lens_np).to(dev)
+    L.check(L.lib().cm_gae(P, T, L.ptr(r_d), L.ptr(b_d), L.ptr(l_d), 0.99, 0.97, 1, 1e-8, L.ptr(adv), None))
     want = O.normalize_advantages(O.gae(r, b, 0.99, 0.97), lens_np)
     np.testing.assert_allclose(adv.cpu().numpy(), want, rtol=2e-4, atol=2e-4)
