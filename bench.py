@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""bench.py - headline benchmark of the Com-MARL hot path on MI355X.
+
+Metric (BASELINE.json): env-steps/sec, whole job, PredatorPrey map=10 sen=1 den=0.04 cap=2
+(N=M=4), 4096 batched envs per GPU, Comm-DP GNN policy.  One "step" = one pass of the hot
+path over the batch: fused policy forward + categorical sample (cm_policy_forward) and the env
+step with auto-reset (cm_env_step), both writing straight into the HBM trajectory buffers.
+Inputs are resident in HBM when the timed region starts; synthetic data = envs spawned by the
+reference's spawn rule on the Philox stream, random-init policy weights (reference init).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (contract fields + "roofline" + "cpu_baseline" + "train_loop").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # BASELINE.json configs[1] - the configuration the metric is quoted on
+    "pp_map10": dict(scenario="pp", map=10, sen=1, n_agents=4, n_preys=4, load=2, max_env_steps=200, loss=0.0,
+                     envs=4096, label="PredatorPrey map=10 sen=1 den=0.04 cap=2 (N=M=4), Comm-DP GNN policy"),
+    "co_map20": dict(scenario="co", map=20, sen=2, n_agents=24, n_preys=0, load=2, max_env_steps=400, loss=0.0,
+                     envs=2048, label="Coverage map=20 sen=2 den=0.06 (N=24), Comm-DP GNN policy"),
+    "pp_map30": dict(scenario="pp", map=30, sen=2, n_agents=72, n_preys=72, load=4, max_env_steps=200, loss=0.0,
+                     envs=1024, label="PredatorPrey map=30 sen=2 den=0.08 cap=4 (N=M=72), Comm-DP GNN policy"),
+    "co_map30": dict(scenario="co", map=30, sen=2, n_agents=54, n_preys=0, load=2, max_env_steps=400, loss=0.3,
+                     envs=1024, label="Coverage map=30 sen=2 den=0.06 loss=0.3 IID (N=54), Comm-DP GNN policy"),
+}
+
+
+def env_params(c):
+    pp = c["scenario"] == "pp"
+    return dict(load=c["load"], max_env_steps=c["max_env_steps"], capture_reward=10 if pp else 2,
+                step_cost=0.1 if pp else 0, rm=0, penalty=0 if pp else 1, revisit_penalty=0.5, lazy_penalty=1,
+                grid_size=c["map"], Rsen=c["sen"], n_agents=c["n_agents"], n_preys=c["n_preys"], n_gcn_layers=2,
+                mode="train", trRcom=9, trpl=c["loss"], obstComplex="Easy", add_clock=0)
+
+
+def algorithmic_bytes(c, d, adj_const, ch_const, L=2):
+    """bytes one env-step must move (env kernel, policy kernel)."""
+    N, M, pp = c["n_agents"], c["n_preys"], c["scenario"] == "pp"
+    G = c["map"] if pp else c["map"] + 2
+    adj = 0 if adj_const else 4 * N * N
+    ch = 0 if ch_const else 4 * L * N * N
+    b_env = 4 * N + 16 * N + ((16 * M + 2 * M) if pp else (2 * (G * G) // 8)) + 8 + 4 * N * d + 5 + adj + ch
+    b_pol = 4 * N * d + adj + ch + 4 * N + 20 * N + 4 * N * N
+    return b_env, b_pol
+
+
+def policy_flops(c, d, L=2):
+    """FLOPs of one policy forward per env (2 x MACs): encoder, attention, L hops, head."""
+    N = c["n_agents"]
+    per_agent = 2 * (d * 128 + 128 * 64 + 64 * 64 + N * 64 + L * (64 * 64 + N * 64) + 64 * 128 + 128 * 64 + 64 * 32 + 32 * 5)
+    return per_agent * N
+
+
+def cpu_baseline(c, seed, budget_s=12.0):
+    """CPU restatement (oracle/, kind 'port') of the same step - C env step + C policy forward +
+    sampler, OpenMP over envs on all host cores - timed on a bounded sample of the workload."""
+    import numpy as np
+    from oracle import oracle as O
+    cores = len(os.sched_getaffinity(0))
+    B = min(c["envs"], 1024)
+    cfg = O.make_cfg(c["scenario"], B, c["n_agents"], c["map"], c["sen"], n_preys=c["n_preys"], load=c["load"],
+                     max_steps=c["max_env_steps"], channel="IID" if 0 < c["loss"] < 1 else "FC", ploss=c["loss"],
+                     seed=seed, rng_mode=O.RNG_PHILOX)
+    env = O.OracleEnv(cfg)
+    import torch
+    from com_marl_amd import envs as E, nets
+    spec = E.EnvSpec(E._Box(np.zeros(env.d * env.N), np.ones(env.d * env.N)), E._Discrete(5))
+    torch.manual_seed(seed)
+    pol = nets.CommCategoricalMLPPolicy(spec, n_agents=env.N, device="cpu")      # weights only; never run on CPU
+    sd = {k: v.detach().numpy() for k, v in pol.state_dict().items()}
+    ones = np.ones((B, env.N, 5), np.float32)
+    env.reset()
+
+    def one(t):
+        probs, _ = O.policy_forward(sd, env.obs, ones, env.dist_adj, env.channels, env.N, n_threads=cores)
+        env.step(O.sample_actions(probs, seed, 0, t), n_threads=cores)
+    one(0)
+    one(1)
+    t0 = time.perf_counter()
+    for t in range(3):
+        one(2 + t)
+    per = max((time.perf_counter() - t0) / 3, 1e-4)
+    n = int(max(3, min(5000, budget_s / per)))
+    t0 = time.perf_counter()
+    for t in range(n):
+        one(5 + t)
+    dt = time.perf_counter() - t0
+    return dict(value=B * n / dt, unit="env-steps/s", cores=cores, kind="port",
+                sample=f"{n} steps x {B} envs of the same workload (C oracle: env step + policy forward + sample, "
+                       f"OpenMP over envs), {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--config", default="pp_map10", choices=sorted(CONFIGS))
+    ap.add_argument("--envs", type=int, default=None, help="envs per GPU (default: the config's)")
+    ap.add_argument("--chunk", type=int, default=50, help="steps per captured hipGraph")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-loop", action="store_true")
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs the MI355X; there is no CPU path")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    from com_marl_amd import envs as E, nets
+    from com_marl_amd.rollout import RolloutEngine
+
+    c = dict(CONFIGS[args.config])
+    B = args.envs or c["envs"]
+    c["envs"] = B
+    env = E.GridEnvBatch(c["scenario"], env_params(c), B, device=dev, seed=args.seed, env_id_offset=rank * B)
+    spec = E.EnvSpec(E._Box(np.zeros(env.d * env.N), np.ones(env.d * env.N)), E._Discrete(5))
+    torch.manual_seed(args.seed)                       # replicas: identical weights on every rank
+    policy = nets.CommCategoricalMLPPolicy(spec, n_agents=env.N, device=dev)
+    policy.set_rng(args.seed, env_id_offset=rank * B)
+    G = max(1, min(args.chunk, args.steps))
+    eng = RolloutEngine(env, policy, horizon=G)
+    eng.reset()
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+
+    def run(n):
+        full, rest = divmod(n, G)
+        for _ in range(full):
+            eng.run_chunk(use_graph=not args.no_graph)
+        for t in range(rest):                          # remainder steps outside the captured chunk
+            eng.step(t)
+            if t == rest - 1:
+                eng.obs[0].copy_(eng.obs[rest])
+                if eng.dist_adj is not None:
+                    eng.dist_adj[0].copy_(eng.dist_adj[rest])
+                if eng.channels is not None:
+                    eng.channels[0].copy_(eng.channels[rest])
+
+    run(args.warmup)
+    env.check_status()
+    barrier()
+    t0 = time.perf_counter()
+    run(args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    env.check_status()
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    value = world * B * args.steps / dt
+
+    # ---- per-kernel durations with HIP events on the launch stream (eager, back-to-back launches) ----
+    def time_kernel(fn, reps=20, inner=10):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        tot = 0.0
+        for _ in range(reps):
+            ev0.record()
+            for _ in range(inner):
+                fn()
+            ev1.record()
+            ev1.synchronize()
+            tot += ev0.elapsed_time(ev1)
+        return tot / (reps * inner) * 1e-3                 # seconds per launch
+
+    t_pol = time_kernel(lambda: policy.act_device(
+        eng.obs[0].view(B, -1), None, None if eng.dist_adj is None else eng.dist_adj[0],
+        None if eng.channels is None else eng.channels[0], out_actions=eng.actions[0], out_probs=eng.probs[0],
+        out_attn=eng.attn[0], policy_step=0, step_base=eng.step_base))
+    t_env = time_kernel(lambda: env.step_device(eng.actions[0], out=eng._out(0)))
+    env.check_status()
+    b_env, b_pol = algorithmic_bytes(c, env.d, env.adj_const, env.ch_const)
+    flops = policy_flops(c, env.d) * B
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(args.config)
+        except Exception:
+            traffic = None
+    kernels = {
+        "cm_policy_forward": dict(bound="mfma", achieved=flops / t_pol / 1e12, peak=157.3, unit="TFLOP/s",
+                                  frac=flops / t_pol / 1e12 / 157.3, us=t_pol * 1e6,
+                                  hbm_GBps=b_pol * B / t_pol / 1e9),
+        "cm_env_step": dict(bound="hbm", achieved=b_env * B / t_env / 1e9, peak=8000.0, unit="GB/s",
+                            frac=b_env * B / t_env / 1e9 / 8000.0, us=t_env * 1e6),
+    }
+    dom = "cm_policy_forward" if t_pol >= t_env else "cm_env_step"
+    roofline = dict(kernel=dom, **{k: kernels[dom][k] for k in ("bound", "achieved", "peak", "unit", "frac")},
+                    traffic=(traffic or {}).get(dom) if isinstance(traffic, dict) else None,
+                    kernels=kernels,
+                    hot_path=dict(bound="hbm", achieved=(b_env + b_pol) * B * args.steps / dt / 1e9 / world, peak=8000.0,
+                                  unit="GB/s", frac=(b_env + b_pol) * B * args.steps / dt / 1e9 / world / 8000.0,
+                                  bytes_per_env_step=b_env + b_pol))
+
+    out = {
+        "metric": "env-steps/sec (whole job), rollout = fused policy forward + sample + env step with auto-reset",
+        "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 (policy GEMMs) + int32/u8 (grid state)", "data": "synthetic",
+        "config": {"workload": c["label"], "envs_per_gpu": B, "total_envs": B * world, "n_agents": c["n_agents"],
+                   "obs_dim": env.d, "graph_chunk": 0 if args.no_graph else G,
+                   "parallelism": f"env-sharded x{world} (no data-path collective in the rollout)"},
+        "roofline": roofline,
+    }
+    if rank == 0 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(c, args.seed)
+    if not args.no_train_loop:
+        try:
+            from com_marl_amd.train_bench import train_loop_measurement
+            out["train_loop"] = train_loop_measurement(env, policy, c, spec, world, rank, dev, args.seed)
+        except ImportError:
+            out["train_loop"] = None
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

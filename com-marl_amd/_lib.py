@@ -31,7 +31,7 @@ class RngTape(C.Structure):
 
 class StepOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("obs", "reward", "reward_f64", "done", "details", "dist_adj", "channels",
-                                          "prey_alive", "success")]
+                                          "prey_alive", "success", "path_len")]
 
 
 class EnvState(C.Structure):
@@ -69,8 +69,8 @@ _SIGNATURES = {
     "cm_env_get_state": (C.c_int, [C.c_void_p, C.POINTER(EnvState)]),
     "cm_env_set_state": (C.c_int, [C.c_void_p, C.POINTER(EnvState)]),
     "cm_policy_forward": (C.c_int, [C.POINTER(PolicyWeights), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
-                                    C.c_void_p, C.c_uint64, C.c_int32, C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p,
-                                    C.c_void_p, C.c_void_p]),
+                                    C.c_void_p, C.c_uint64, C.c_int32, C.c_uint32, C.c_void_p, C.c_int32, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]),
     "cm_critic_forward": (C.c_int, [C.POINTER(CriticWeights), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p]),
     "cm_masked_agg_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -1,0 +1,294 @@
+"""CentralizedMAPPO - the PPO update of com_marl/torch/algos/centralized_ma_ppo.py:39-659 with
+the trajectory resident in HBM.
+
+Same ctor kwargs and the same numbers:
+returns f64 recurrence -> f32, GAE over the padded length with V of padded steps as the critic
+outputs them, per-path advantage normalisation (biased variance, eps 1e-8), clip range fixed at
+0.1, entropy bonus, mean over valid steps, Gaussian-NLL critic loss over padded steps, grad-clip
+on the policy only, two Adam optimisers (lr 3e-4, eps 1e-5), minibatches over shuffled paths.
+
+What changed is where it runs: the padded [P,T,...] batch is gathered on the device from the
+sampler's time-major buffers; returns / GAE / normalisation are HIP scan kernels
+(cm_discount_returns, cm_gae); critic baselines, old-policy log-likelihoods and the KL/entropy
+diagnostics are fused no-grad launches; the training forward shares ONE trunk evaluation for the
+entropy and the new log-likelihood (the reference runs it twice); multi-GPU adds one RCCL
+all-reduce of the flat (policy ‖ critic ‖ counts) gradient bucket per optimiser step.
+"""
+import collections
+import copy
+import time
+
+import numpy as np
+import torch
+from torch.distributions import Categorical
+
+from . import _lib as L
+from .sampler import CentralizedMAOnPolicyVectorizedSampler, PathBatch, tabular
+
+
+def _dist_ready():
+    from .dist import is_distributed
+    return is_distributed()
+
+
+class CentralizedMAPPO:
+    def __init__(self, env_spec, policy, baseline, optimizer=None, baseline_optimizer=None,
+                 optimization_n_minibatches=1, optimization_mini_epochs=1, policy_lr=3e-4, lr_clip_range=2e-1,
+                 max_path_length=500, num_train_per_epoch=1, discount=0.99, gae_lambda=1, center_adv=True,
+                 positive_adv=False, policy_ent_coeff=0.0, use_softplus_entropy=False, stop_entropy_gradient=False,
+                 entropy_method='no_entropy', clip_grad_norm=None, device='cpu'):
+        self.device = device
+        self.env_spec, self.policy, self.baseline = env_spec, policy, baseline
+        self.discount, self.max_path_length, self.n_samples = discount, max_path_length, num_train_per_epoch
+        self._gae_lambda, self._center_adv, self._positive_adv = gae_lambda, center_adv, positive_adv
+        self._policy_ent_coeff = policy_ent_coeff
+        self._use_softplus_entropy, self._stop_entropy_gradient = use_softplus_entropy, stop_entropy_gradient
+        self._entropy_method = entropy_method
+        self._lr_clip_range = 0.1                       # hard-coded in the reference (:115); ctor arg ignored
+        self._eps = 1e-8
+        self._maximum_entropy = entropy_method == 'max'
+        self._entropy_regularzied = entropy_method == 'regularized'
+        self._check_entropy_configuration(entropy_method, center_adv, stop_entropy_gradient, policy_ent_coeff)
+        if use_softplus_entropy or self._maximum_entropy or stop_entropy_gradient:
+            raise NotImplementedError("only the runners' entropy settings ('regularized' / 'no_entropy') are built")
+        opt = optimizer or torch.optim.Adam
+        bopt = baseline_optimizer or torch.optim.Adam
+        # torch.optim.Adam (foreach=False) is the same update as the vendored torch-1.9 Adam
+        # (my_optimizer/_functional.py:72-98): pinned by tests against the reference's optimiser.
+        self._optimizer = opt(policy.parameters(), lr=policy_lr, eps=1e-5)
+        self._baseline_optimizer = bopt(baseline.parameters(), lr=policy_lr, eps=1e-5)
+        self._optimization_n_minibatches = optimization_n_minibatches
+        self._optimization_mini_epochs = optimization_mini_epochs
+        self._clip_grad_norm = clip_grad_norm
+        self._old_policy = copy.deepcopy(self.policy)
+        self._old_policy._pack_sig, self._old_policy._pack = None, None
+        self.sampler_cls = CentralizedMAOnPolicyVectorizedSampler
+        self.episode_reward_mean = collections.deque(maxlen=100)
+        self.stats = {}
+
+    @staticmethod
+    def _check_entropy_configuration(entropy_method, center_adv, stop_entropy_gradient, policy_ent_coeff):
+        if entropy_method not in ('max', 'regularized', 'no_entropy'):
+            raise ValueError('Invalid entropy_method')
+        if entropy_method == 'max':
+            if center_adv:
+                raise ValueError('center_adv should be False when entropy_method is max')
+            if not stop_entropy_gradient:
+                raise ValueError('stop_gradient should be True when entropy_method is max')
+        if entropy_method == 'no_entropy' and policy_ent_coeff != 0.0:
+            raise ValueError('policy_ent_coeff should be zero when there is no entropy method')
+
+    # ------------------------------------------------------------------------------------------
+    # process_samples (:612-659)
+    # ------------------------------------------------------------------------------------------
+    def _dev(self):
+        return next(self.policy.parameters()).device
+
+    def process_samples(self, itr, paths):
+        """-> (obs [P,T,N*d], avail (None = ones), actions [P,T,N], rewards [P,T] f32, valids [P] int32,
+        baselines [P,T], returns [P,T], dist_adjs [P,T,N,N]|None, channels [P,T,L,N,N]|None), all on device.
+        Zero padding for obs/actions/rewards/returns, ONE padding for the masks (App. A-5)."""
+        dev = self._dev()
+        if isinstance(paths, PathBatch):
+            e = paths.engine
+            lens = paths.length
+            P, T = lens.numel(), int(lens.max().item())
+            tau = torch.arange(T, device=dev)
+            valid = tau[None, :] < lens[:, None]                                  # [P,T]
+            t_idx = (paths.start[:, None] + tau[None, :]).clamp_(max=e.obs.shape[0] - 2)
+            b_idx = paths.env_idx[:, None].expand(P, T)
+
+            def gather(buf, pad):
+                x = buf[t_idx, b_idx]                                              # [P,T,...]
+                m = valid.reshape(P, T, *([1] * (x.dim() - 2)))
+                return torch.where(m, x, torch.full((), pad, dtype=x.dtype, device=dev))
+            obs = gather(e.obs, 0).reshape(P, T, -1)
+            actions = gather(e.actions, 0)
+            rew64 = gather(e.reward64, 0)
+            dist_adjs = None if e.dist_adj is None else gather(e.dist_adj, 1)
+            channels = None if e.channels is None else gather(e.channels, 1)
+            valids = lens.to(torch.int32)
+        else:                                                                       # reference list-of-dicts
+            P = len(paths)
+            T = max(len(p['rewards']) for p in paths)
+            N = self.policy._n_agents
+            Lh = len(self.policy.gcn_layers)
+
+            def pad(key, val, dtype, tail):
+                out = torch.full((P, T) + tail, val, dtype=dtype)
+                for i, p in enumerate(paths):
+                    a = torch.as_tensor(np.asarray(p[key])).to(dtype).reshape((-1,) + tail)
+                    out[i, :a.shape[0]] = a
+                return out.to(dev)
+            obs = pad('observations', 0, torch.float32, (paths[0]['observations'].shape[-1],))
+            actions = pad('actions', 0, torch.int32, (N,))
+            rew64 = pad('rewards', 0, torch.float64, ())
+            dist_adjs = pad('dist_adjs', 1, torch.float32, (N, N))
+            channels = pad('channels', 1, torch.float32, (Lh, N, N))
+            valids = torch.tensor([len(p['actions']) for p in paths], dtype=torch.int32, device=dev)
+        self.temp_max_path_length = T
+        rewards = rew64.to(torch.float32).contiguous()                              # torch.Tensor(path['rewards']) (:645)
+        returns = torch.empty(P, T, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            L.check(L.lib().cm_discount_returns(P, T, L.ptr(rew64.contiguous()), L.ptr(valids), float(self.discount),
+                                                L.ptr(returns), L.current_stream()), "cm_discount_returns")
+        with torch.no_grad():                                                       # :653-655
+            baselines = self.baseline.forward(obs, None, dist_adjs, channels)
+        return obs, None, actions, rewards, valids, baselines, returns, dist_adjs, channels
+
+    # ------------------------------------------------------------------------------------------
+    # loss pieces
+    # ------------------------------------------------------------------------------------------
+    def _advantages(self, rewards, baselines, valids):
+        """compute_advantages + per-path normalisation (:418-426) in one scan kernel."""
+        P, T = rewards.shape
+        adv = torch.empty_like(rewards)
+        with torch.cuda.device(rewards.device):
+            L.check(L.lib().cm_gae(P, T, L.ptr(rewards.contiguous()), L.ptr(baselines.contiguous()), L.ptr(valids),
+                                   float(self.discount), float(self._gae_lambda), int(self._center_adv), self._eps,
+                                   L.ptr(adv), L.current_stream()), "cm_gae")
+        if self._positive_adv:
+            adv = adv - adv.min()
+        return adv
+
+    @torch.no_grad()
+    def _old_log_likelihood(self, obs, actions, dist_adjs, channels):
+        """old_policy.log_likelihood (:561-566): one fused no-grad launch."""
+        P, T = obs.shape[:2]
+        N = self.policy._n_agents
+        flat = lambda x: None if x is None else x.reshape(P * T, *x.shape[2:])      # noqa: E731
+        _, probs, _ = self._old_policy.act_device(flat(obs), None, flat(dist_adjs), flat(channels), want_actions=False,
+                                                  want_attn=False, policy_step=0)
+        lp = torch.log(probs.gather(-1, actions.reshape(P * T, N, 1).long())).squeeze(-1)
+        return lp.sum(-1).reshape(P, T)
+
+    def _valid_mask(self, valids, T):
+        return torch.arange(T, device=valids.device)[None, :] < valids[:, None]
+
+    def _compute_loss(self, itr, obs, avail_actions, actions, rewards, valids, baselines, dist_adjs, channels,
+                      advantages=None, old_ll=None, reduce=True):
+        """:390-438.  Returns -(mean over valid steps of clipped surrogate + c * entropy); with
+        reduce=False returns (sum, count) for the count-weighted multi-GPU reduction."""
+        T = obs.shape[1]
+        if advantages is None:
+            advantages = self._advantages(rewards, baselines, valids)
+        if old_ll is None:
+            old_ll = self._old_log_likelihood(obs, actions, dist_adjs, channels)
+        probs, _ = self.policy._probs(obs, avail_actions, dist_adjs, channels)      # one trunk pass for both terms
+        dist_n = Categorical(probs=probs)
+        entropies = dist_n.entropy().mean(-1)                                        # policy.entropy (:121-126)
+        new_ll = dist_n.log_prob(actions).sum(-1)                                    # policy.log_likelihood (:128-137)
+        ratio = (new_ll - old_ll).exp()
+        surrogate = ratio * advantages
+        clipped = torch.clamp(ratio, min=1 - self._lr_clip_range, max=1 + self._lr_clip_range) * advantages
+        objective = torch.min(surrogate, clipped)                                    # :540-589
+        if self._entropy_regularzied:
+            objective = objective + self._policy_ent_coeff * entropies               # :434-435
+        mask = self._valid_mask(valids, T)
+        total = -(objective * mask).sum()
+        count = mask.sum()
+        if not reduce:
+            return total, count
+        return total / count
+
+    @torch.no_grad()
+    def _diagnostics(self, obs, actions, valids, dist_adjs, channels):
+        """KL(old || new) mean and policy entropy mean over ALL padded steps, as :440-538 compute them."""
+        P, T = obs.shape[:2]
+        flat = lambda x: None if x is None else x.reshape(P * T, *x.shape[2:])      # noqa: E731
+        _, p_new, _ = self.policy.act_device(flat(obs), None, flat(dist_adjs), flat(channels), want_actions=False,
+                                             want_attn=False, policy_step=0)
+        _, p_old, _ = self._old_policy.act_device(flat(obs), None, flat(dist_adjs), flat(channels),
+                                                  want_actions=False, want_attn=False, policy_step=0)
+        kl = (p_old * (torch.log(p_old) - torch.log(p_new))).sum(-1).mean()
+        ent = -(p_new * torch.log(p_new)).sum(-1).mean(-1).mean()
+        return float(kl), float(ent)
+
+    # ------------------------------------------------------------------------------------------
+    # gradient exchange
+    # ------------------------------------------------------------------------------------------
+    def _allreduce_grads(self, n_valid, n_crit):
+        """One RCCL all-reduce of [policy grads ‖ critic grads ‖ n_valid ‖ n_crit] (dist.allreduce_sum_grads)."""
+        from .dist import allreduce_sum_grads
+        allreduce_sum_grads(list(self.policy.parameters()), list(self.baseline.parameters()), n_valid, n_crit)
+
+    # ------------------------------------------------------------------------------------------
+    # train_once (:175-388)
+    # ------------------------------------------------------------------------------------------
+    def train_once(self, runner=None, itr=None, paths=None):
+        if runner is not None:
+            itr, paths = runner.step_itr, runner.step_path
+        t_start = time.time()
+        obs, avail, actions, rewards, valids, baselines, returns, dist_adjs, channels = self.process_samples(itr, paths)
+        P, T = rewards.shape
+        distributed = _dist_ready()
+        advantages = self._advantages(rewards, baselines, valids)
+        with torch.no_grad():
+            old_ll0 = self._old_log_likelihood(obs, actions, dist_adjs, channels)
+            loss_before = float(self._compute_loss(itr, obs, avail, actions, rewards, valids, baselines, dist_adjs,
+                                                   channels, advantages, old_ll0))
+            kl_before, _ = self._diagnostics(obs, actions, valids, dist_adjs, channels)
+        self._old_policy.load_state_dict(self.policy.state_dict())                  # :204
+        with torch.no_grad():
+            old_ll = self._old_log_likelihood(obs, actions, dist_adjs, channels)
+
+        step_size = int(np.ceil(P / self._optimization_n_minibatches))
+        shuffled_ids = np.random.permutation(P)                                      # :209
+        grad_norm = []
+        sl = lambda x, ids: None if x is None else x[ids]                            # noqa: E731
+        t_opt = time.time()
+        for mini_epoch in range(self._optimization_mini_epochs):
+            for start in range(0, P, step_size):
+                ids = torch.as_tensor(shuffled_ids[start:min(start + step_size, P)], device=obs.device)
+                o, a, r, v = obs[ids], actions[ids], rewards[ids], valids[ids]
+                da, ch = sl(dist_adjs, ids), sl(channels, ids)
+                loss_sum, n_valid = self._compute_loss(itr, o, None, a, r, v, baselines[ids], da, ch,
+                                                       advantages[ids], old_ll[ids], reduce=False)
+                # critic: Gaussian NLL, mean over padded steps (comm_base_critic.py:88-89)
+                n_crit = torch.tensor(float(o.shape[0] * T), device=obs.device)
+                self._baseline_optimizer.zero_grad()
+                self._optimizer.zero_grad()
+                if distributed:
+                    (self.baseline.compute_loss(o, returns[ids], da, ch) * n_crit).backward()
+                    loss_sum.backward()
+                    self._allreduce_grads(n_valid, n_crit)
+                else:
+                    self.baseline.compute_loss(o, returns[ids], da, ch).backward()
+                    (loss_sum / n_valid).backward()
+                if self._clip_grad_norm is not None:                                 # policy only (:253-255)
+                    torch.nn.utils.clip_grad_norm_(self.policy.parameters(), self._clip_grad_norm)
+                grad_norm.append(self.policy.grad_norm())
+                self._optimizer.step()                                               # _optimize (:606-610)
+                self._baseline_optimizer.step()
+        torch.cuda.synchronize(obs.device)
+        epoch_time = time.time() - t_opt
+        self.policy.sync_weights()
+
+        with torch.no_grad():
+            loss_after = float(self._compute_loss(itr, obs, avail, actions, rewards, valids, baselines, dist_adjs,
+                                                  channels, advantages, old_ll))
+            kl, entropy = self._diagnostics(obs, actions, valids, dist_adjs, channels)
+        mask = self._valid_mask(valids, T)
+        undisc = (rewards * mask).sum(1)
+        avg_return = float(undisc.mean())
+        self.episode_reward_mean.extend(undisc.tolist())
+        self.stats = dict(AverageReturn=avg_return, NumTrajs=P, LossBefore=loss_before, LossAfter=loss_after,
+                          dLoss=loss_before - loss_after, KLBefore=kl_before, KL=kl, Entropy=entropy,
+                          GradNorm=float(np.mean(grad_norm)) if grad_norm else 0.0, EpochTime=epoch_time,
+                          TrainOnceTime=time.time() - t_start, MaxPathLength=T,
+                          EnvSteps=int(valids.sum().item()))
+        for k, v in self.stats.items():
+            tabular.record(k, v)
+        return avg_return
+
+    def train(self, runner):
+        """MABatchPolopt.train (com_marl/np/algos/ma_batch_polopt.py:72-120): sample -> train_once per epoch."""
+        last_return = None
+        for _epoch in runner.step_epochs():
+            if getattr(runner, "flag", [0])[0]:
+                break
+            for _ in range(self.n_samples):
+                runner.step_path = runner.obtain_samples(runner.step_itr)
+                last_return = self.train_once(runner)
+                runner.step_itr += 1
+        return last_return

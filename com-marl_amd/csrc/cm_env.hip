@@ -469,6 +469,7 @@ __global__ __launch_bounds__(WAVE) void env_kernel(EnvDev p, const int32_t *__re
         if (out.reward) out.reward[b] = (float)reward;
         if (out.reward_f64) out.reward_f64[b] = reward;
         if (out.done) out.done[b] = (uint8_t)done;
+        if (out.path_len) out.path_len[b] = done ? step_count : 0;
         if (out.details) for (int k = 0; k < 6; ++k) out.details[(size_t)b * 6 + k] = det[k];
         p.rng_step[b] = rng.step + 1;
     }

@@ -35,6 +35,7 @@ struct FwdArgs {
     int S, N, d, L, EPB;
     const float *obs, *avail, *adj, *chan;
     uint32_t key0, key1, policy_step;
+    const uint32_t *step_base;
     int env_id_offset, greedy;
     int32_t *actions;
     float *probs, *attn, *values;
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(TPB) void fwd_kernel(FwdArgs a, TrunkW tw, PolHead 
                     for (int c = 1; c < A; ++c) if (p[c] > p[act]) act = c;
                 } else {                                        // inverse CDF on one Philox uniform per agent
                     const int e = r / N, i = r - e * N;
-                    const u32x4 xr = philox4x32_10((uint32_t)(a.env_id_offset + s0 + e), a.policy_step, SITE_ACTION, (uint32_t)i, a.key0, a.key1);
+                    const u32x4 xr = philox4x32_10((uint32_t)(a.env_id_offset + s0 + e), a.policy_step + (a.step_base ? *a.step_base : 0u), SITE_ACTION, (uint32_t)i, a.key0, a.key1);
                     const float u = unit_f32(xr.x);
                     float acc = 0.0f;
                     int sel = -1, last = 0;
@@ -270,8 +271,8 @@ using namespace cm;
 
 extern "C" int cm_policy_forward(const cm_policy_weights *w, int32_t n_samples, const float *obs, const float *avail,
                                  const float *dist_adj, const float *channels, uint64_t seed, int32_t env_id_offset,
-                                 uint32_t policy_step, int32_t greedy, int32_t *actions, float *probs, float *attn,
-                                 void *stream) {
+                                 uint32_t policy_step, const uint32_t *policy_step_base, int32_t greedy,
+                                 int32_t *actions, float *probs, float *attn, void *stream) {
     if (!w || !obs) return set_error(CM_ERR_ARG, "cm_policy_forward: null weights / obs");
     if (n_samples <= 0) return CM_OK;
     if (w->enc_hidden != EH || w->emb != EMB || w->h1 != H1 || w->h2 != H2 || w->h3 != H3)
@@ -281,7 +282,7 @@ extern "C" int cm_policy_forward(const cm_policy_weights *w, int32_t n_samples, 
     FwdArgs a{};
     a.S = n_samples; a.N = w->n_agents; a.d = w->d; a.L = w->n_hops;
     a.obs = obs; a.avail = avail; a.adj = dist_adj; a.chan = channels;
-    a.key0 = (uint32_t)seed; a.key1 = (uint32_t)(seed >> 32); a.policy_step = policy_step;
+    a.key0 = (uint32_t)seed; a.key1 = (uint32_t)(seed >> 32); a.policy_step = policy_step; a.step_base = policy_step_base;
     a.env_id_offset = env_id_offset; a.greedy = greedy;
     a.actions = actions; a.probs = probs; a.attn = attn;
     TrunkW tw{ w->enc_w1t, w->enc_b1, w->enc_w2t, w->enc_b2, w->attn_wt, w->gcn_w, w->gcn_b };

@@ -136,11 +136,11 @@ class GridEnvBatch:
         o = dict(obs=self.obs, reward=self.reward, reward_f64=self.reward64, done=self.done, details=self.details,
                  dist_adj=None if self.adj_const else self.dist_adj,
                  channels=None if self.ch_const else self.channels,
-                 prey_alive=self.prey_alive if self.M else None, success=self.success_t)
+                 prey_alive=self.prey_alive if self.M else None, success=self.success_t, path_len=None)
         if over:
             o.update(over)
         return L.StepOut(*[L.ptr(o[k]) for k in ("obs", "reward", "reward_f64", "done", "details", "dist_adj",
-                                                 "channels", "prey_alive", "success")])
+                                                 "channels", "prey_alive", "success", "path_len")])
 
     def _tape(self, tape):
         if not tape:

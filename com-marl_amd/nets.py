@@ -223,29 +223,38 @@ class CommBaseNet(nn.Module):
         raise NotImplementedError
 
     def _packed(self):
-        """Flat contiguous device copy of the (transposed) weights, rebuilt when any parameter changed."""
+        """Flat contiguous device copy of the (transposed) weights.  Allocated once; when a parameter
+        changed (optimizer step / load_state_dict) the SAME buffer is rewritten in place, so device
+        pointers - and any hipGraph that captured them - stay valid."""
         sig = tuple((p.data_ptr(), p._version) for p in self.parameters())
-        if sig != self._pack_sig:
-            with torch.no_grad():
-                ts = self._trunk_tensors()
-                ts.update(self._head_tensors())
-                flat, offs, off = [], {}, 0
+        if sig == self._pack_sig:
+            return self._pack[1]
+        with torch.no_grad():
+            ts = self._trunk_tensors()
+            ts.update(self._head_tensors())
+            if self._pack is None or self._pack[0].device != next(self.parameters()).device:
+                offs, off = {}, 0
                 for k, v in ts.items():
                     if v is None:
                         offs[k] = None
                         continue
-                    v = v.detach().to(torch.float32).contiguous().reshape(-1)
-                    pad = (-v.numel()) % 4                      # keep every tensor 16-byte aligned
-                    offs[k] = off
-                    flat.append(v)
-                    if pad:
-                        flat.append(torch.zeros(pad, dtype=torch.float32, device=v.device))
-                    off += v.numel() + pad
-                buf = torch.cat(flat)
+                    offs[k] = (off, v.numel())
+                    off += (v.numel() + 3) & ~3                 # keep every tensor 16-byte aligned
+                buf = torch.zeros(off, dtype=torch.float32, device=next(self.parameters()).device)
                 base = buf.data_ptr()
-                self._pack = (buf, {k: (None if o is None else base + 4 * o) for k, o in offs.items()})
-                self._pack_sig = sig
+                ptrs = {k: (None if o is None else base + 4 * o[0]) for k, o in offs.items()}
+                self._pack = (buf, ptrs, offs)
+            buf, ptrs, offs = self._pack
+            for k, v in ts.items():
+                if v is not None:
+                    o, n = offs[k]
+                    buf[o:o + n].copy_(v.detach().to(torch.float32).reshape(-1))
+            self._pack_sig = sig
         return self._pack[1]
+
+    def sync_weights(self):
+        """Refresh the fused kernels' weight pack (call after an optimizer step, outside graphs)."""
+        self._packed()
 
 
 # ---------------------------------------------------------------------------------------------
@@ -329,7 +338,7 @@ class CommCategoricalMLPPolicy(CommBaseNet):
 
     @torch.no_grad()
     def act_device(self, obs, avail, dist_adj, channels, greedy=False, want_actions=True, want_probs=True,
-                   want_attn=True, out_actions=None, out_probs=None, out_attn=None, policy_step=None):
+                   want_attn=True, out_actions=None, out_probs=None, out_attn=None, policy_step=None, step_base=None):
         """Fused forward on device tensors: obs [S,N*d]|[S,N,d]; avail/dist_adj/channels may be None
         (= all ones).  Returns (actions int32 [S,N], probs [S,N,A], attn [S,N,N]) as CUDA tensors."""
         dev = obs.device
@@ -353,7 +362,7 @@ class CommCategoricalMLPPolicy(CommBaseNet):
                 C.byref(w), S, L.ptr(obs), L.ptr(None if avail is None else avail.contiguous()),
                 L.ptr(None if dist_adj is None else dist_adj.contiguous()),
                 L.ptr(None if channels is None else channels.contiguous()), self.seed, self.env_id_offset,
-                policy_step & 0xFFFFFFFF, int(greedy), L.ptr(actions), L.ptr(probs), L.ptr(attn),
+                policy_step & 0xFFFFFFFF, L.ptr(step_base), int(greedy), L.ptr(actions), L.ptr(probs), L.ptr(attn),
                 L.current_stream()), "cm_policy_forward")
         return actions, probs, attn
 

@@ -1,0 +1,116 @@
+"""Device-resident rollout engine: the inner loop of
+CentralizedMAOnPolicyVectorizedSampler.obtain_samples (com_marl/sampler/
+centralized_ma_on_policy_vectorized_sampler.py:119-232) for B envs at once.
+
+One step = two kernel launches, no host synchronisation and no copies:
+    policy forward + sample  (cm_policy_forward)  reads  obs[t], dist_adj[t], channels[t]
+                                                   writes actions[t], probs[t], attn[t]
+    env step + auto-reset    (cm_env_step)        reads  actions[t]
+                                                   writes obs[t+1], reward[t], done[t], ... , dist_adj[t+1], channels[t+1]
+The trajectory buffers are time-major [H(+1), B, ...] in HBM, so every step reads and writes
+contiguous [B, ...] slabs and the kernels write straight into them (zero-copy).  A chunk of
+steps can be captured into a hipGraph and replayed (the launch-bound regime at 4096 x N=4).
+"""
+import torch
+
+from . import _lib as L
+
+
+class RolloutEngine:
+    def __init__(self, env, policy, horizon, store_attn=True, store_probs=True):
+        """env: envs.GridEnvBatch; policy: nets.CommCategoricalMLPPolicy on the same device."""
+        self.env, self.policy, self.H = env, policy, int(horizon)
+        dev, B, N, M, d, Lh = env.device, env.B, env.N, max(env.M, 1), env.d, env.Lh
+        A = policy._action_dim
+        H = self.H
+        f32, i32, u8 = torch.float32, torch.int32, torch.uint8
+        z = lambda *shape, dtype=f32: torch.zeros(*shape, dtype=dtype, device=dev)   # noqa: E731
+        self.obs = z(H + 1, B, N, d)
+        self.actions = z(H, B, N, dtype=i32)
+        self.probs = z(H, B, N, A) if store_probs else None
+        self.attn = z(H, B, N, N) if store_attn else None
+        self.reward = z(H, B)
+        self.reward64 = z(H, B, dtype=torch.float64)
+        self.done = z(H, B, dtype=u8)
+        self.details = z(H, B, 6, dtype=i32)
+        self.prey_alive = z(H, B, M, dtype=u8) if env.M else None
+        self.success = z(H, B, dtype=i32)
+        self.path_len = z(H, B, dtype=i32)
+        # constant masks are never stored per step (4N^2 [adj != const] rule of SURVEY.md §8d)
+        self.dist_adj = None if env.adj_const else z(H + 1, B, N, N)
+        self.channels = None if env.ch_const else z(H + 1, B, Lh, N, N)
+        self.step_base = torch.zeros(1, dtype=i32, device=dev)      # device-side Philox counter base (uint32 bits)
+        self._graphs = {}
+        self.t = 0
+
+    # ------------------------------------------------------------------------------------------
+    def _out(self, t):
+        o = dict(obs=self.obs[t + 1], reward=self.reward[t], reward_f64=self.reward64[t], done=self.done[t],
+                 details=self.details[t], success=self.success[t], path_len=self.path_len[t])
+        if self.prey_alive is not None:
+            o["prey_alive"] = self.prey_alive[t]
+        if self.dist_adj is not None:
+            o["dist_adj"] = self.dist_adj[t + 1]
+        if self.channels is not None:
+            o["channels"] = self.channels[t + 1]
+        return o
+
+    def reset(self):
+        """VecEnvExecutor.reset: every env restarts; slot 0 receives the first observation."""
+        o = dict(obs=self.obs[0])
+        if self.dist_adj is not None:
+            o["dist_adj"] = self.dist_adj[0]
+        if self.channels is not None:
+            o["channels"] = self.channels[0]
+        self.env.reset_all(out=o)
+        self.t = 0
+
+    def step(self, t, greedy=False):
+        """Slot t -> t+1 (asynchronous)."""
+        B = self.env.B
+        self.policy.act_device(
+            self.obs[t].view(B, -1), None,
+            None if self.dist_adj is None else self.dist_adj[t],
+            None if self.channels is None else self.channels[t],
+            greedy=greedy, out_actions=self.actions[t],
+            out_probs=None if self.probs is None else self.probs[t],
+            out_attn=None if self.attn is None else self.attn[t],
+            want_probs=self.probs is not None, want_attn=self.attn is not None,
+            policy_step=t, step_base=self.step_base)
+        self.env.step_device(self.actions[t], out=self._out(t))
+
+    def _wrap(self):
+        """Carry the last slot of the previous chunk into slot 0 (what `obses = next_obses` does)."""
+        self.obs[0].copy_(self.obs[self.H])
+        if self.dist_adj is not None:
+            self.dist_adj[0].copy_(self.dist_adj[self.H])
+        if self.channels is not None:
+            self.channels[0].copy_(self.channels[self.H])
+
+    def run_chunk(self, use_graph=True):
+        """H steps filling every slot; with use_graph the chunk is one hipGraph replay."""
+        if not use_graph:
+            for t in range(self.H):
+                self.step(t)
+            self.step_base.add_(self.H)
+            self._wrap()
+            return
+        g = self._graphs.get("chunk")
+        if g is None:
+            # warm-up outside capture: first-call attribute setup + weight pack must not be captured
+            self.step(0)
+            torch.cuda.synchronize(self.env.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for t in range(self.H):
+                    self.step(t)
+                self.step_base.add_(self.H)
+                self._wrap()
+            self._graphs["chunk"] = g
+        self.policy.sync_weights()          # in-place refresh of the weight pack the graph points at
+        g.replay()
+
+    def invalidate_graphs(self):
+        """Call after the policy weights were re-packed at a new address (never needed when
+        parameters are updated in place: the pack buffer is rewritten, see nets._packed)."""
+        self._graphs.clear()

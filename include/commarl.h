@@ -93,6 +93,8 @@ typedef struct cm_step_out {
     float *channels;         /* [B,L,N,N] */
     uint8_t *prey_alive;     /* [B,M] env_infos['prey_alive'] (pre-reset) */
     int32_t *success;        /* [B] env.success after the step */
+    int32_t *path_len;       /* [B] length of the path that ended at this step (0 = still running):
+                                what the sampler adds to n_samples, x N (sampler.py:225) */
 } cm_step_out;
 
 /* Host-side snapshot of the SoA state (for parity fixtures / checkpoints). */
@@ -162,11 +164,13 @@ typedef struct cm_critic_weights {
  * head -> softmax x avail -> renorm -> sample (inverse CDF on the Philox stream) or argmax.
  *   obs [S,N,d]; avail [S,N,A] or NULL (= all ones, predatorprey_wrapper.py:46-51);
  *   dist_adj [S,N,N] or NULL (= ones); channels [S,L,N,N] or NULL (= ones);
- *   out: actions int32 [S,N] (or NULL), probs [S,N,A] (or NULL), attn [S,N,N] (or NULL). */
+ *   out: actions int32 [S,N] (or NULL), probs [S,N,A] (or NULL), attn [S,N,N] (or NULL).
+ *   The sampler's Philox counter word is policy_step + (policy_step_base ? *policy_step_base : 0);
+ *   the device-side base lets a captured hipGraph be replayed with fresh draws. */
 int cm_policy_forward(const cm_policy_weights *w, int32_t n_samples, const float *obs, const float *avail,
                       const float *dist_adj, const float *channels, uint64_t seed, int32_t env_id_offset,
-                      uint32_t policy_step, int32_t greedy, int32_t *actions, float *probs, float *attn,
-                      void *stream);
+                      uint32_t policy_step, const uint32_t *policy_step_base, int32_t greedy, int32_t *actions,
+                      float *probs, float *attn, void *stream);
 
 /* CommBaseCritic.forward (comm_base_critic.py:91-114): values [S] = sum over agents. */
 int cm_critic_forward(const cm_critic_weights *w, int32_t n_samples, const float *obs, const float *dist_adj,

@@ -489,14 +489,93 @@ def record_adam(ns, seed=9, steps=3):
     return dict(grads=np.stack(grads), params=np.stack(params))
 
 
+def record_ppo_step(seed=11):
+    """Two optimiser steps of the reference CentralizedMAPPO on paths from the reference sampler
+    (PP map10, Tmax 12): process_samples tensors, losses, gradients, clipped grad-norm, parameters
+    after each Adam step."""
+    import copy
+    import types
+    ns = ref_loader.load_reference_ppo(ref_loader.load_reference())
+    params = pp_params(10, 1, 0.04, 2, max_env_steps=12)
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    env = ns.PredatorPreyWrapper(centralized=True, params=dict(params))
+    spec = ref_loader.make_env_spec(84)
+
+    class Shell:                      # what GarageEnv adds for the sampler: .spec, attribute passthrough
+        def __init__(self, e):
+            self.__dict__['_e'] = e
+            self.__dict__['spec'] = spec
+
+        def __getattr__(self, k):
+            return getattr(self.__dict__['_e'], k)
+    policy = ns.CommCategoricalMLPPolicy(spec, n_agents=4)
+    critic = ns.CommBaseCritic(spec, n_agents=4)
+    with torch.no_grad():
+        for net in (policy, critic):
+            for name, p in net.named_parameters():
+                if name.endswith('bias') and 'gcn' not in name:
+                    p.uniform_(-0.1, 0.1)
+    algo = ns.CentralizedMAPPO(env_spec=spec, policy=policy, baseline=critic, max_path_length=12, discount=0.99,
+                               center_adv=True, positive_adv=False, gae_lambda=0.97, policy_ent_coeff=0.1,
+                               entropy_method='regularized', stop_entropy_gradient=False, clip_grad_norm=7,
+                               optimization_n_minibatches=3, optimization_mini_epochs=10, device='cpu')
+    sampler = ns.ReferenceSampler(algo, Shell(env), n_envs=1)
+    sampler.start_worker()
+    paths = sampler.obtain_samples(0, batch_size=9 * 12 * 4)
+    # make the batch ragged (random-policy episodes all run to the time limit): keep a prefix of two paths
+    for i, n in ((1, 5), (4, 9)):
+        for k, v in list(paths[i].items()):
+            if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == 12 and k != 'success':
+                paths[i][k] = v[:n]
+    out = {}
+    for name, p in policy.state_dict().items():
+        out['pol0.' + name] = p.clone().numpy()
+    for name, p in critic.state_dict().items():
+        out['crit0.' + name] = p.clone().numpy()
+    obs, avail, actions, rewards, valids, baselines, returns, dist_adjs, channels = algo.process_samples(0, paths)
+    P, T = rewards.shape
+    out.update(obs=obs.numpy(), actions=actions.numpy().astype(np.int32), rewards=rewards.numpy(),
+               valids=valids.numpy(), baselines=baselines.numpy(), returns=returns.numpy(),
+               dist_adjs=dist_adjs.numpy(), channels=channels.numpy(),
+               rewards64=np.stack([np.pad(np.asarray(p['rewards'], np.float64), (0, T - len(p['rewards'])))
+                                   for p in paths]))
+    for step in (1, 2):
+        loss = algo._compute_loss(0, obs, avail, actions, rewards, valids, baselines, dist_adjs, channels)
+        bl = critic.compute_loss(obs, returns, dist_adjs, channels)
+        algo._baseline_optimizer.zero_grad()
+        bl.backward()
+        algo._optimizer.zero_grad()
+        loss.backward()
+        out[f'loss{step}'] = loss.detach().numpy()
+        out[f'critic_loss{step}'] = bl.detach().numpy()
+        for name, p in policy.named_parameters():
+            out[f'gpol{step}.' + name] = p.grad.clone().numpy()
+        for name, p in critic.named_parameters():
+            out[f'gcrit{step}.' + name] = p.grad.clone().numpy()
+        torch.nn.utils.clip_grad_norm_(policy.parameters(), 7)
+        out[f'grad_norm{step}'] = np.float64(policy.grad_norm())
+        algo._optimizer.step()
+        algo._baseline_optimizer.step()
+        for name, p in policy.state_dict().items():
+            out[f'pol{step}.' + name] = p.clone().numpy()
+        for name, p in critic.state_dict().items():
+            out[f'crit{step}.' + name] = p.clone().numpy()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=os.path.join(HERE, '..', 'tests', 'golden'))
+    ap.add_argument('--only', default=None, help='regenerate a single fixture (e.g. ppo_step)')
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     ns = ref_loader.load_reference()
 
     def save(name, d):
+        if args.only and name != args.only:
+            return
         path = os.path.join(args.out, name + '.npz')
         np.savez_compressed(path, **d)
         print(f'{name:28s} {os.path.getsize(path) / 1024:8.1f} KiB')
@@ -543,6 +622,7 @@ def main():
     save('policy_co_map30_iid', record_policy(ns, fx['co_map30_iid'], 54, take=2))
     save('ppo_math', record_ppo_math(ns))
     save('adam', record_adam(ns))
+    save('ppo_step', record_ppo_step())
 
 
 if __name__ == '__main__':

@@ -125,6 +125,8 @@ def _install_third_party_stubs():
 
     # ---- misc --------------------------------------------------------------
     class ProgBar:
+        active = False
+
         def __init__(self, *a, **k):
             pass
 
@@ -232,11 +234,21 @@ def load_reference_ppo(ns=None):
     for n in dir(tu):
         if not n.startswith("_"):
             setattr(sys.modules["garage.torch"], n, getattr(tu, n))
+    sys.modules["garage.tf.samplers"].BatchSampler = object
     try:
+        imp("garage.experiment.deterministic")
+        sys.modules["garage.experiment"].deterministic = sys.modules["garage.experiment.deterministic"]
+        smp = imp("com_marl.sampler.centralized_ma_on_policy_vectorized_sampler")
+        sys.modules["com_marl.sampler"].CentralizedMAOnPolicyVectorizedSampler = \
+            smp.CentralizedMAOnPolicyVectorizedSampler
+        ns.ReferenceSampler = smp.CentralizedMAOnPolicyVectorizedSampler
+        ns.VecEnvExecutor = sys.modules["garage.sampler.vec_env_executor"].VecEnvExecutor
         pol = imp("com_marl.np.algos.ma_batch_polopt")
         sys.modules["com_marl.np.algos"].MABatchPolopt = pol.MABatchPolopt
         ns.CentralizedMAPPO = imp("com_marl.torch.algos.centralized_ma_ppo").CentralizedMAPPO
     except Exception as e:  # pragma: no cover - diagnostic
+        import traceback
+        traceback.print_exc()
         ns.ppo_import_error = e
     return ns
 

@@ -33,7 +33,7 @@ def test_struct_layouts_match_header_sizes():
     from com_marl_amd import _lib
     assert C.sizeof(_lib.EnvCfg) == 16 * 4 + 4 * 4 + 7 * 8 + 8
     assert C.sizeof(_lib.RngTape) == 5 * 8
-    assert C.sizeof(_lib.StepOut) == 9 * 8
+    assert C.sizeof(_lib.StepOut) == 10 * 8
     assert C.sizeof(_lib.EnvState) == 9 * 8
     assert C.sizeof(_lib.PolicyWeights) == 10 * 4 + 15 * 8
     assert C.sizeof(_lib.CriticWeights) == 6 * 4 + 11 * 8
@@ -50,7 +50,7 @@ def test_argument_errors_without_gpu():
     cfg = _lib.EnvCfg()
     cfg.scenario = 7
     assert lib.cm_env_create(C.byref(cfg), C.byref(h)) == -1
-    assert lib.cm_policy_forward(None, 4, None, None, None, None, 0, 0, 0, 0, None, None, None, None) == -1
+    assert lib.cm_policy_forward(None, 4, None, None, None, None, 0, 0, 0, None, 0, None, None, None, None) == -1
     assert lib.cm_gae(0, 0, None, None, None, 0.99, 0.97, 0, 1e-8, None, None) == -1
 
 
