@@ -62,12 +62,25 @@ def policy_flops(c, d, L=2):
     return per_agent * N
 
 
+def host_cores():
+    """Threads the CPU leg may use: the affinity mask, capped by the cgroup CPU quota and by the
+    16-core share a one-GPU box is given."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("COMMARL_CPU_THREADS", "16"))))
+
+
 def cpu_baseline(c, seed, budget_s=12.0):
     """CPU restatement (oracle/, kind 'port') of the same step - C env step + C policy forward +
     sampler, OpenMP over envs on all host cores - timed on a bounded sample of the workload."""
     import numpy as np
     from oracle import oracle as O
-    cores = len(os.sched_getaffinity(0))
+    cores = host_cores()
     B = min(c["envs"], 1024)
     cfg = O.make_cfg(c["scenario"], B, c["n_agents"], c["map"], c["sen"], n_preys=c["n_preys"], load=c["load"],
                      max_steps=c["max_env_steps"], channel="IID" if 0 < c["loss"] < 1 else "FC", ploss=c["loss"],
