@@ -15,6 +15,8 @@
 // stored transposed [in,out] so lanes read consecutive outputs) stream from L2.
 // This file is the f32 VALU version (fmaf chains, k ascending); see DESIGN.md for the
 // f32-MFMA plan.  f32 is required: the parity bar is 1e-5 on probabilities.
+#include <stdlib.h>
+
 #include "cm_internal.h"
 #include "cm_rng.h"
 
@@ -269,6 +271,21 @@ static int launch_fwd(FwdArgs a, const TrunkW &tw, const PolHead &ph, const Crit
 
 using namespace cm;
 
+namespace cm {
+int policy_forward_mfma(const cm_policy_weights *w, int32_t S, const float *obs, const float *avail, const float *adj,
+                        const float *chan, uint64_t seed, int32_t env_id_offset, uint32_t policy_step,
+                        const uint32_t *step_base, int32_t greedy, int32_t *actions, float *probs, float *attn,
+                        void *stream);
+int critic_forward_mfma(const cm_critic_weights *w, int32_t S, const float *obs, const float *adj, const float *chan,
+                        float *values, void *stream);
+}
+
+// COMMARL_POLICY_KERNEL=valu forces the generic VALU kernel (A/B timing, obs dims without an MFMA build)
+static bool use_mfma() {
+    static const bool v = [] { const char *e = getenv("COMMARL_POLICY_KERNEL"); return !(e && e[0] == 'v'); }();
+    return v;
+}
+
 extern "C" int cm_policy_forward(const cm_policy_weights *w, int32_t n_samples, const float *obs, const float *avail,
                                  const float *dist_adj, const float *channels, uint64_t seed, int32_t env_id_offset,
                                  uint32_t policy_step, const uint32_t *policy_step_base, int32_t greedy,
@@ -279,6 +296,11 @@ extern "C" int cm_policy_forward(const cm_policy_weights *w, int32_t n_samples, 
         return set_error(CM_ERR_ARG, "cm_policy_forward: only the reference layer sizes (128 | 64 | 128,64,32) are built");
     if (w->n_act < 1 || w->n_act > MAX_ACT || w->d < 1 || w->d > 2 * SE - 4 || w->n_agents < 1 || w->n_hops < 0)
         return set_error(CM_ERR_ARG, "cm_policy_forward: bad dims");
+    if (use_mfma()) {
+        const int rc = policy_forward_mfma(w, n_samples, obs, avail, dist_adj, channels, seed, env_id_offset, policy_step,
+                                           policy_step_base, greedy, actions, probs, attn, stream);
+        if (rc <= 0) return rc;
+    }
     FwdArgs a{};
     a.S = n_samples; a.N = w->n_agents; a.d = w->d; a.L = w->n_hops;
     a.obs = obs; a.avail = avail; a.adj = dist_adj; a.chan = channels;
@@ -297,6 +319,10 @@ extern "C" int cm_critic_forward(const cm_critic_weights *w, int32_t n_samples, 
     if (w->enc_hidden != EH || w->emb != EMB || w->dec_hidden != DH)
         return set_error(CM_ERR_ARG, "cm_critic_forward: only the reference layer sizes (128 | 64 | 64) are built");
     if (w->d < 1 || w->d > 2 * SE - 4 || w->n_agents < 1 || w->n_hops < 0) return set_error(CM_ERR_ARG, "cm_critic_forward: bad dims");
+    if (use_mfma()) {
+        const int rc = critic_forward_mfma(w, n_samples, obs, dist_adj, channels, values, stream);
+        if (rc <= 0) return rc;
+    }
     FwdArgs a{};
     a.S = n_samples; a.N = w->n_agents; a.d = w->d; a.L = w->n_hops;
     a.obs = obs; a.adj = dist_adj; a.chan = channels; a.values = values;

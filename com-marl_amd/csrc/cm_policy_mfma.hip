@@ -1,0 +1,413 @@
+// cm_policy_mfma.hip - fused Comm-DP policy / critic forward on the gfx950 matrix cores.
+//
+// Same computation and C-ABI as cm_policy.hip (reference:
+// com_marl/torch/policies/comm_categorical_mlp_policy.py:48-119, modules/comm_base_net.py:80-108,
+// attention_module.py:26-51, graph_conv_module.py:51-72, baselines/comm_base_critic.py:91-114),
+// with every dense per-agent layer on v_mfma_f32_16x16x4_f32 (f32 in / f32 accumulate: exact
+// f32, needed for the 1e-5 parity bar; this is the 157 TFLOP/s roof the kernel is priced on).
+//
+// Work decomposition (256 threads = 4 waves per workgroup, EPB whole envs = rows agent rows):
+//   * activations live in LDS [rows_pad][stride] with stride == 2 (mod 32) words, so the A-operand
+//     read  A[row = lane&15][k = 4*kk + (lane>>4)]  is bank-conflict free;
+//   * a wave owns 1-2 column tiles (16 outputs) of a layer and ALL row tiles: its B fragments
+//     (weights, k-major [in][out], read from L2 once per layer per wave) sit in registers for the
+//     whole layer, two row tiles are accumulated alternately so the 40-cycle dependent-accumulator
+//     latency of the 16x16x4 instruction is covered by the 32-cycle issue of the other tile;
+//   * the tiny per-env parts (N x N attention softmax, mask + renorm, A.(HW), 32->5 head,
+//     categorical sample) stay on the VALU against the same LDS tiles.
+// HBM traffic is the algorithmic minimum: obs (+ masks) in, actions / probs / attention out.
+#include <stdlib.h>
+
+#include "cm_internal.h"
+#include "cm_rng.h"
+
+namespace cm {
+namespace mf {
+
+constexpr int TPB = 256;
+constexpr int EH = 128, EMB = 64, H1 = 128, H2 = 64, H3 = 32, DH = 64;
+constexpr int SA = 132;        // row strides (words): multiples of 4 so every lane's A chunk is a 16-byte
+constexpr int SE = 68;         // aligned ds_read_b128; the +4 skews rows across banks
+constexpr int MAX_ACT = 8;
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// tanh(x) = 1 - 2 / (exp(2x) + 1) on the hardware exp2 / rcp units: ~8 instructions instead of the
+// ~40 of the libm-grade tanhf.  Absolute error <= 2e-7 over the whole range (measured against
+// double tanh in tests/test_hip_policy_parity.py), far inside the 1e-5 parity bar; saturates to
+// +-1 without NaN (exp -> inf gives 1 - 0, exp -> 0 gives 1 - 2).
+__device__ __forceinline__ float fast_tanh(float x) {
+    const float t = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);     // exp(2x) = 2^(2x*log2 e)
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);
+}
+
+struct TrunkW { const float *enc_w1t, *enc_b1, *enc_w2t, *enc_b2, *attn_wt, *gcn_w, *gcn_b; };
+struct PolHead { const float *w1t, *b1, *w2t, *b2, *w3t, *b3, *w4t, *b4; int n_act; };
+struct CritHead { const float *w1t, *b1, *w2t, *b2; };
+struct FwdArgs {
+    int S, N, d, L, EPB;
+    const float *obs, *avail, *adj, *chan;
+    uint32_t key0, key1, policy_step;
+    const uint32_t *step_base;
+    int env_id_offset, greedy;
+    int32_t *actions;
+    float *probs, *attn, *values;
+    int stop;          // diagnostic: return after phase `stop` (0 = run everything); COMMARL_FWD_STOP
+};
+
+// One dense layer  out[r][o] = act(sum_k in[r][k] * Wt[k][o] + bias[o]),  r < 16*row_tiles, o < OUT,
+// k < kreal <= KPAD.  load() pulls this wave's B fragments (weights) into registers - it is issued one
+// layer AHEAD of run() so the L2 latency hides under the previous layer's MFMAs; run() streams the A
+// operand from LDS.
+template <int KPAD, int OUT>
+struct Layer {
+    static constexpr int CT = OUT / 16;                // column tiles of the layer
+    static constexpr int NCT = CT >= 4 ? CT / 4 : 1;   // column tiles per wave
+    static constexpr int KS = KPAD / 4;                // k-steps
+    float b[NCT][KS];
+    float bv[NCT];
+
+    // k-slot mapping of the 16x16x4 MFMA: lane group g = lane>>4 supplies k = 16*kq + 4*g + j at step
+    // (kq, j).  Each lane's A operands are then 4 CONTIGUOUS words per kq (one ds_read_b128), all of a
+    // row tile's reads are issued up front and the MFMAs run back to back behind counted waits.
+    __device__ __forceinline__ void load(const float *__restrict__ Wt, const float *__restrict__ bias, int kreal,
+                                         int wave, int lane, int out_real = OUT) {
+        const int ct0 = CT >= 4 ? wave * NCT : (wave % CT);
+        const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int t = 0; t < NCT; ++t) {
+            const int col = (ct0 + t) * 16 + c;
+            const bool cok = col < out_real;
+            bv[t] = (bias && cok) ? bias[col] : 0.0f;
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                const int k = 16 * (kk >> 2) + 4 * g + (kk & 3);
+                b[t][kk] = (k < kreal && cok) ? Wt[(size_t)k * out_real + col] : 0.0f;
+            }
+        }
+    }
+
+    template <bool TANH>
+    __device__ __forceinline__ void run(const float *in, int in_stride, float *out, int out_stride, int row_tiles,
+                                        int wave, int lane) const {
+        const int ct0 = CT >= 4 ? wave * NCT : (wave % CT);
+        const int rt_start = CT >= 4 ? 0 : wave / CT;
+        const int rt_step = CT >= 4 ? 1 : 4 / CT;
+        const int c = lane & 15, g = lane >> 4;
+        for (int rt = rt_start; rt < row_tiles; rt += 2 * rt_step) {
+            const int rtB = rt + rt_step;
+            const bool hasB = rtB < row_tiles;
+            const float4 *pa = reinterpret_cast<const float4 *>(in + (size_t)(rt * 16 + c) * in_stride + 4 * g);
+            const float4 *pb = reinterpret_cast<const float4 *>(in + (size_t)((hasB ? rtB : rt) * 16 + c) * in_stride + 4 * g);
+            float4 a0[KS / 4], a1[KS / 4];
+#pragma unroll
+            for (int kq = 0; kq < KS / 4; ++kq) { a0[kq] = pa[4 * kq]; a1[kq] = pb[4 * kq]; }
+            v4f acc0[NCT], acc1[NCT];
+#pragma unroll
+            for (int t = 0; t < NCT; ++t) { acc0[t] = (v4f){ 0.f, 0.f, 0.f, 0.f }; acc1[t] = (v4f){ 0.f, 0.f, 0.f, 0.f }; }
+#pragma unroll
+            for (int kq = 0; kq < KS / 4; ++kq) {
+                const float x0[4] = { a0[kq].x, a0[kq].y, a0[kq].z, a0[kq].w };
+                const float x1[4] = { a1[kq].x, a1[kq].y, a1[kq].z, a1[kq].w };
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int t = 0; t < NCT; ++t) {
+                        acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[j], b[t][4 * kq + j], acc0[t], 0, 0, 0);
+                        acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[j], b[t][4 * kq + j], acc1[t], 0, 0, 0);
+                    }
+                }
+            }
+            // D layout: col = lane&15, row = 4*(lane>>4) + reg
+#pragma unroll
+            for (int t = 0; t < NCT; ++t) {
+                const int col = (ct0 + t) * 16 + c;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v0 = acc0[t][r] + bv[t];
+                    out[(size_t)(rt * 16 + 4 * g + r) * out_stride + col] = TANH ? fast_tanh(v0) : v0;
+                    if (hasB) {
+                        const float v1 = acc1[t][r] + bv[t];
+                        out[(size_t)(rtB * 16 + 4 * g + r) * out_stride + col] = TANH ? fast_tanh(v1) : v1;
+                    }
+                }
+            }
+        }
+    }
+};
+
+__host__ __device__ inline size_t lds_floats(int rows_pad, int epb, int N) {
+    const int NP = N | 1;
+    return (size_t)rows_pad * (SA + 3 * SE) + (size_t)epb * N * NP + rows_pad;
+}
+
+template <int HEAD, int KPAD>   // HEAD 0 = policy, 1 = critic; KPAD = obs dim rounded up to 16
+__global__ __launch_bounds__(TPB) void fwd_mfma_kernel(FwdArgs a, TrunkW tw, PolHead ph, CritHead chd) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int N = a.N, d = a.d, L = a.L, NN = N * N, NP = N | 1;
+    const int s0 = blockIdx.x * a.EPB;
+    const int envs = min(a.EPB, a.S - s0);
+    const int rows = envs * N, rows_cap = (a.EPB * N + 15) & ~15, RT = (rows + 15) >> 4;
+    float *bufA = lds;                                  // [rows_cap][SA]
+    float *E = bufA + (size_t)rows_cap * SA;            // [rows_cap][SE]
+    float *H = E + (size_t)rows_cap * SE;               // [rows_cap][SE]
+    float *T = H + (size_t)rows_cap * SE;               // [rows_cap][SE]
+    float *M = T + (size_t)rows_cap * SE;               // [EPB*N][NP]
+    float *rs = M + (size_t)a.EPB * N * NP;             // [rows_cap]
+    float *X = H;                                       // obs staging [rows_cap][SX] over H|T
+    constexpr int SX = 2 * SE;                          // 136 words: d <= 128
+
+    Layer<KPAD, EH> l_enc1;
+    l_enc1.load(tw.enc_w1t, tw.enc_b1, d, wave, lane);
+    Layer<EH, EMB> l_enc2;
+    l_enc2.load(tw.enc_w2t, tw.enc_b2, EH, wave, lane);
+    // ---- stage observations (coalesced), zero the k-padding and the padded rows ----
+    {
+        const float *src = a.obs + (size_t)s0 * N * d;
+        const int total = RT * 16 * KPAD;
+        for (int k = tid; k < total; k += TPB) {
+            const int r = k / KPAD, f = k - r * KPAD;
+            X[(size_t)r * SX + f] = (r < rows && f < d) ? src[(size_t)r * d + f] : 0.0f;
+        }
+    }
+    __syncthreads();
+    if (a.stop == 1) return;
+    l_enc1.template run<true>(X, SX, bufA, SA, RT, wave, lane);
+    Layer<EMB, EMB> l_sq;                               // 64x64 square layers: attention, then the GCN hops
+    l_sq.load(tw.attn_wt, nullptr, EMB, wave, lane);
+    __syncthreads();
+    if (a.stop == 2) return;
+    l_enc2.template run<true>(bufA, SA, E, SE, RT, wave, lane);
+    __syncthreads();
+    if (a.stop == 3) return;
+    l_sq.template run<false>(E, SE, T, SE, RT, wave, lane);                                  // Q = E.Wa^T
+    if (L > 0) l_sq.load(tw.gcn_w, nullptr, EMB, wave, lane);
+    __syncthreads();
+    if (a.stop == 4) return;
+    // ---- attention scores + softmax (VALU, N x N per env) ----
+    for (int k = tid; k < envs * NN; k += TPB) {
+        const int e = k / NN, ij = k - e * NN, i = ij / N, j = ij - i * N;
+        const float4 *q = reinterpret_cast<const float4 *>(T + (size_t)(e * N + i) * SE);
+        const float4 *c = reinterpret_cast<const float4 *>(E + (size_t)(e * N + j) * SE);
+        float acc = 0.0f;
+#pragma unroll
+        for (int kk = 0; kk < EMB / 4; ++kk) {
+            const float4 x = q[kk], y = c[kk];
+            acc = fmaf(x.x, y.x, acc); acc = fmaf(x.y, y.y, acc); acc = fmaf(x.z, y.z, acc); acc = fmaf(x.w, y.w, acc);
+        }
+        M[(size_t)(e * N + i) * NP + j] = acc;
+    }
+    __syncthreads();
+    for (int r = tid; r < rows; r += TPB) {
+        float *m = M + (size_t)r * NP;
+        float mx = -INFINITY, sum = 0.0f;
+        for (int j = 0; j < N; ++j) mx = fmaxf(mx, m[j]);
+        for (int j = 0; j < N; ++j) { const float ex = expf(m[j] - mx); m[j] = ex; sum += ex; }
+        for (int j = 0; j < N; ++j) m[j] = m[j] / sum;
+    }
+    __syncthreads();
+    if (a.attn) {
+        float *dst = a.attn + (size_t)s0 * NN;
+        for (int k = tid; k < envs * NN; k += TPB) { const int r = k / N, j = k - r * N; dst[k] = M[(size_t)r * NP + j]; }
+    }
+    if (a.stop == 5) return;
+    // ---- L GCN hops: HW on the matrix cores, masked aggregation on the VALU ----
+    float *Amat = bufA;                                 // [rows][NP]
+    for (int l = 0; l < L; ++l) {
+        const float *Hin = (l == 0) ? E : H;
+        l_sq.template run<false>(Hin, SE, T, SE, RT, wave, lane);                              // H.Wg_l
+        if (l + 1 < L) l_sq.load(tw.gcn_w + (size_t)(l + 1) * EMB * EMB, nullptr, EMB, wave, lane);
+        for (int k = tid; k < envs * NN; k += TPB) {    // A = M * Range * Chan_l (coalesced mask reads)
+            const int e = k / NN, ij = k - e * NN, r = k / N, j = k - r * N;
+            float v = M[(size_t)r * NP + j];
+            if (a.adj) v *= a.adj[(size_t)(s0 + e) * NN + ij];
+            if (a.chan) v *= a.chan[((size_t)(s0 + e) * L + l) * NN + ij];
+            Amat[(size_t)r * NP + j] = v;
+        }
+        __syncthreads();
+        for (int r = tid; r < rows; r += TPB) {
+            float *ar = Amat + (size_t)r * NP;
+            float sum = 0.0f;
+            for (int j = 0; j < N; ++j) sum += ar[j];
+            const float den = sum + 1e-12f;
+            for (int j = 0; j < N; ++j) ar[j] = ar[j] / den;
+        }
+        __syncthreads();
+        {
+            const int o = tid & (EMB - 1), rg = tid >> 6;
+            const float bv = tw.gcn_b ? tw.gcn_b[(size_t)l * EMB + o] : 0.0f;
+            for (int r0 = rg * 4; r0 < rows; r0 += 16) {
+                const int e = r0 / N;
+                const float *hw = T + (size_t)e * N * SE + o;
+                float acc[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+                const float *ar[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ar[i] = Amat + (size_t)min(r0 + i, rows - 1) * NP;
+                for (int j = 0; j < N; ++j) {
+                    const float h = hw[(size_t)j * SE];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i] = fmaf(ar[i][j], h, acc[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (r0 + i < rows && (r0 + i) / N == e) H[(size_t)(r0 + i) * SE + o] = fast_tanh(acc[i] + bv);
+            }
+        }
+        __syncthreads();
+    }
+    if (a.stop == 6) return;
+    // ---- residual ----
+    for (int k = tid; k < rows * EMB; k += TPB) {
+        const int r = k >> 6, o = k & 63;
+        H[(size_t)r * SE + o] = E[(size_t)r * SE + o] + (L > 0 ? H[(size_t)r * SE + o] : 0.0f);
+    }
+    __syncthreads();
+
+    if (HEAD == 0) {
+        Layer<EMB, H1> l_h1;
+        l_h1.load(ph.w1t, ph.b1, EMB, wave, lane);
+        Layer<H1, H2> l_h2;
+        l_h2.load(ph.w2t, ph.b2, H1, wave, lane);
+        l_h1.template run<true>(H, SE, bufA, SA, RT, wave, lane);
+        Layer<H2, H3> l_h3;
+        l_h3.load(ph.w3t, ph.b3, H2, wave, lane);
+        __syncthreads();
+        l_h2.template run<true>(bufA, SA, T, SE, RT, wave, lane);
+        const int A = ph.n_act;
+        Layer<H3, 16> l_h4;                              // 32 -> n_act (<= 8) logits, zero-padded to one column tile
+        l_h4.load(ph.w4t, ph.b4, H3, wave, lane, A);
+        __syncthreads();
+        l_h3.template run<true>(T, SE, E, SE, RT, wave, lane);
+        __syncthreads();
+        if (a.stop == 7) return;
+        l_h4.template run<false>(E, SE, bufA, SA, RT, wave, lane);
+        __syncthreads();
+        for (int r = tid; r < rows; r += TPB) {
+            float lg[MAX_ACT], p[MAX_ACT];
+            const float *x = bufA + (size_t)r * SA;
+#pragma unroll
+            for (int c = 0; c < MAX_ACT; ++c) lg[c] = (c < A) ? x[c] : 0.0f;
+            float mx = -INFINITY, sum = 0.0f, msum = 0.0f;
+#pragma unroll
+            for (int c = 0; c < MAX_ACT; ++c) if (c < A) mx = fmaxf(mx, lg[c]);
+#pragma unroll
+            for (int c = 0; c < MAX_ACT; ++c) if (c < A) { p[c] = expf(lg[c] - mx); sum += p[c]; }
+            const size_t grow = (size_t)s0 * N + r;
+#pragma unroll
+            for (int c = 0; c < MAX_ACT; ++c) if (c < A) {
+                const float av = a.avail ? a.avail[grow * A + c] : 1.0f;
+                p[c] = (p[c] / sum) * av; msum += p[c];
+            }
+#pragma unroll
+            for (int c = 0; c < MAX_ACT; ++c) if (c < A) p[c] = p[c] / msum;
+            if (a.probs) {
+#pragma unroll
+                for (int c = 0; c < MAX_ACT; ++c) if (c < A) a.probs[grow * A + c] = p[c];
+            }
+            if (a.actions) {
+                int act = 0;
+                if (a.greedy) {
+                    float best = p[0];
+#pragma unroll
+                    for (int c = 1; c < MAX_ACT; ++c) if (c < A && p[c] > best) { best = p[c]; act = c; }
+                } else {
+                    const int e = r / N, i = r - e * N;
+                    const u32x4 xr = philox4x32_10((uint32_t)(a.env_id_offset + s0 + e),
+                                                   a.policy_step + (a.step_base ? *a.step_base : 0u), SITE_ACTION,
+                                                   (uint32_t)i, a.key0, a.key1);
+                    const float u = unit_f32(xr.x);
+                    float acc = 0.0f;
+                    int sel = -1, last = 0;
+#pragma unroll
+                    for (int c = 0; c < MAX_ACT; ++c) if (c < A) { if (p[c] > 0.0f) last = c; acc += p[c]; if (sel < 0 && u < acc) sel = c; }
+                    act = sel < 0 ? last : sel;
+                }
+                a.actions[grow] = act;
+            }
+        }
+    } else {
+        Layer<EMB, DH> l_d1;
+        l_d1.load(chd.w1t, chd.b1, EMB, wave, lane);
+        l_d1.template run<true>(H, SE, T, SE, RT, wave, lane);
+        __syncthreads();
+        for (int r = tid; r < rows; r += TPB) {
+            const float *x = T + (size_t)r * SE;
+            float acc = chd.b2 ? chd.b2[0] : 0.0f;
+            for (int k = 0; k < DH; ++k) acc = fmaf(x[k], chd.w2t[k], acc);
+            rs[r] = acc;
+        }
+        __syncthreads();
+        for (int e = tid; e < envs; e += TPB) {
+            float v = 0.0f;
+            for (int i = 0; i < N; ++i) v += rs[e * N + i];
+            a.values[s0 + e] = v;
+        }
+    }
+}
+
+static int pick_epb(int N) {
+    if (N % 4 != 0) return 1;                 // aggregation tiles must not straddle envs
+    static const int target = [] { const char *e = getenv("COMMARL_FWD_ROWS"); return e ? atoi(e) : 32; }();
+    const int e = target / N;                 // ~32 rows per workgroup: 2 row tiles, >= 2 workgroups per CU
+    return e > 0 ? e : 1;
+}
+
+template <int HEAD, int KPAD>
+static int launch(FwdArgs a, const TrunkW &tw, const PolHead &ph, const CritHead &chd, void *stream) {
+    a.EPB = pick_epb(a.N);
+    const int rows_cap = (a.EPB * a.N + 15) & ~15;
+    const size_t lds = lds_floats(rows_cap, a.EPB, a.N) * sizeof(float);
+    if (lds > 160 * 1024) return set_error(CM_ERR_ARG, "policy forward: n_agents too large for the 160 KB LDS tile");
+    static bool attr_set = false;
+    if (!attr_set) {
+        CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fwd_mfma_kernel<HEAD, KPAD>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const int blocks = (a.S + a.EPB - 1) / a.EPB;
+    hipLaunchKernelGGL((fwd_mfma_kernel<HEAD, KPAD>), dim3(blocks), dim3(TPB), lds, (hipStream_t)stream, a, tw, ph, chd);
+    CM_HIP(hipGetLastError());
+    return CM_OK;
+}
+
+template <int HEAD>
+static int dispatch(const FwdArgs &a, const TrunkW &tw, const PolHead &ph, const CritHead &chd, void *stream) {
+    const int kpad = (a.d + 15) & ~15;
+    switch (kpad) {      // obs dims of the reference scenarios: PP sen1 21, CO sen1 29, PP sen2 53, CO sen2 77 (+clock 78)
+    case 32: return launch<HEAD, 32>(a, tw, ph, chd, stream);
+    case 64: return launch<HEAD, 64>(a, tw, ph, chd, stream);
+    case 80: return launch<HEAD, 80>(a, tw, ph, chd, stream);
+    default: return 1;   // caller falls back to the generic VALU kernel
+    }
+}
+
+}  // namespace mf
+
+// entry points used by cm_policy.hip's C-ABI functions; return 1 when the obs dim has no MFMA instantiation
+int policy_forward_mfma(const cm_policy_weights *w, int32_t S, const float *obs, const float *avail, const float *adj,
+                        const float *chan, uint64_t seed, int32_t env_id_offset, uint32_t policy_step,
+                        const uint32_t *step_base, int32_t greedy, int32_t *actions, float *probs, float *attn,
+                        void *stream) {
+    mf::FwdArgs a{};
+    a.S = S; a.N = w->n_agents; a.d = w->d; a.L = w->n_hops;
+    a.obs = obs; a.avail = avail; a.adj = adj; a.chan = chan;
+    a.key0 = (uint32_t)seed; a.key1 = (uint32_t)(seed >> 32); a.policy_step = policy_step; a.step_base = step_base;
+    a.env_id_offset = env_id_offset; a.greedy = greedy;
+    a.actions = actions; a.probs = probs; a.attn = attn;
+    { const char *e = getenv("COMMARL_FWD_STOP"); a.stop = e ? atoi(e) : 0; }
+    mf::TrunkW tw{ w->enc_w1t, w->enc_b1, w->enc_w2t, w->enc_b2, w->attn_wt, w->gcn_w, w->gcn_b };
+    mf::PolHead ph{ w->hd_w1t, w->hd_b1, w->hd_w2t, w->hd_b2, w->hd_w3t, w->hd_b3, w->hd_w4t, w->hd_b4, w->n_act };
+    return mf::dispatch<0>(a, tw, ph, mf::CritHead{}, stream);
+}
+
+int critic_forward_mfma(const cm_critic_weights *w, int32_t S, const float *obs, const float *adj, const float *chan,
+                        float *values, void *stream) {
+    mf::FwdArgs a{};
+    a.S = S; a.N = w->n_agents; a.d = w->d; a.L = w->n_hops;
+    a.obs = obs; a.adj = adj; a.chan = chan; a.values = values;
+    mf::TrunkW tw{ w->enc_w1t, w->enc_b1, w->enc_w2t, w->enc_b2, w->attn_wt, w->gcn_w, w->gcn_b };
+    mf::CritHead chd{ w->dec_w1t, w->dec_b1, w->dec_w2t, w->dec_b2 };
+    return mf::dispatch<1>(a, tw, mf::PolHead{}, chd, stream);
+}
+
+}  // namespace cm
