@@ -192,18 +192,25 @@ def main():
         dt = float(tt.item())
     value = world * B * args.steps / dt
 
-    # ---- per-kernel durations with HIP events on the launch stream (eager, back-to-back launches) ----
-    def time_kernel(fn, reps=20, inner=10):
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        tot = 0.0
-        for _ in range(reps):
-            ev0.record()
+    # ---- per-kernel durations with HIP events on the launch stream.  The launches are replayed from a
+    # captured hipGraph of `inner` back-to-back launches (as in the timed region), so the figure is the
+    # GPU-side launch-to-launch period (kernel + ~1.5 us boundary), not Python's call overhead. ----
+    def time_kernel(fn, reps=10, inner=20):
+        fn()
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
             for _ in range(inner):
                 fn()
-            ev1.record()
-            ev1.synchronize()
-            tot += ev0.elapsed_time(ev1)
-        return tot / (reps * inner) * 1e-3                 # seconds per launch
+        g.replay()
+        torch.cuda.synchronize(dev)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(reps):
+            g.replay()
+        ev1.record()
+        ev1.synchronize()
+        return ev0.elapsed_time(ev1) / (reps * inner) * 1e-3                 # seconds per launch
 
     t_pol = time_kernel(lambda: policy.act_device(
         eng.obs[0].view(B, -1), None, None if eng.dist_adj is None else eng.dist_adj[0],
