@@ -7,7 +7,8 @@
 // (predator_prey.py:173-204, coverage.py:198-212,448-480) and update_communication_state
 // (custom_implement/env_communication.py:91-157,200-243; gilbert_elliot_loss_model.py:121-150).
 //
-// Mapping: ONE WAVEFRONT (64 lanes) PER ENV, one single-wave workgroup per env.
+// Mapping: a single-wave workgroup steps G = 64/LPE envs, LPE = 16 / 32 / 64 lanes per env (the smallest
+// group that gives each agent / prey a lane): at N = 4 four envs share a wave and run in lockstep.
 //   * SoA state lives in HBM ([B,N] int2 positions, [B,M] alive bytes, [B,S] visited row
 //     bitmasks ...); a step reads it once, rebuilds the S x S occupancy tile in LDS (the
 //     reference's string grid is derived state and never stored), and writes it back once.
@@ -44,7 +45,7 @@ __device__ __forceinline__ void raise(const EnvDev &p, int code) { atomicCAS(p.s
 // the compiler keeps the accesses in the LDS address space (ds_read/ds_write), never as flat pointers.
 extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-struct Lds {           // byte offsets into smem
+struct Lds {           // byte offsets into smem (kept in registers: always passed by value)
     int g;             // [S*S] u8 occupancy tile
     int ar, ac;        // [N] i16
     int pr, pc;        // [M] i16
@@ -53,48 +54,57 @@ struct Lds {           // byte offsets into smem
     int pcnt;          // [M] u8 predator count around prey j
     int pmv;           // [M] u8 chosen prey move | 8 = tape ran out
     int vis;           // [S] u32
+#ifdef CM_BOUNDS
     int nS2, nN, nM, nS;
     int32_t *status;
+#endif
 };
 
 __host__ __device__ inline int lds_take(int &off, int bytes) { const int o = off; off += (bytes + 15) & ~15; return o; }
-__host__ __device__ inline size_t lds_layout(int S, int N, int M, Lds *l) {
+__host__ __device__ inline int lds_env_bytes(int S, int N, int M) {
     int off = 0;
-    const int g = lds_take(off, S * S), ar = lds_take(off, 2 * N), ac = lds_take(off, 2 * N), pr = lds_take(off, 2 * M),
-              pc = lds_take(off, 2 * M), act = lds_take(off, N), alive = lds_take(off, M), pcnt = lds_take(off, M),
-              pmv = lds_take(off, M), vis = lds_take(off, 4 * S);
-    if (l) {
-        l->g = g; l->ar = ar; l->ac = ac; l->pr = pr; l->pc = pc; l->act = act; l->alive = alive; l->pcnt = pcnt;
-        l->pmv = pmv; l->vis = vis; l->nS2 = S * S; l->nN = N; l->nM = M; l->nS = S;
-    }
-    return (size_t)off;
+    lds_take(off, S * S); lds_take(off, 2 * N); lds_take(off, 2 * N); lds_take(off, 2 * M); lds_take(off, 2 * M);
+    lds_take(off, N); lds_take(off, M); lds_take(off, M); lds_take(off, M); lds_take(off, 4 * S);
+    return off;
+}
+__device__ __forceinline__ Lds make_lds(int S, int N, int M, int base, int32_t *status) {
+    int off = base;
+    Lds l;
+    l.g = lds_take(off, S * S); l.ar = lds_take(off, 2 * N); l.ac = lds_take(off, 2 * N); l.pr = lds_take(off, 2 * M);
+    l.pc = lds_take(off, 2 * M); l.act = lds_take(off, N); l.alive = lds_take(off, M); l.pcnt = lds_take(off, M);
+    l.pmv = lds_take(off, M); l.vis = lds_take(off, 4 * S);
+#ifdef CM_BOUNDS
+    l.nS2 = S * S; l.nN = N; l.nM = M; l.nS = S; l.status = status;
+#endif
+    return l;
 }
 
 // -DCM_BOUNDS builds a checked variant: an out-of-range LDS index raises status -100-site instead of
 // silently reading 0 (LDS out-of-range reads are not faults), used to hunt indexing bugs on the GPU.
 #ifdef CM_BOUNDS
-__device__ __forceinline__ int chk(const Lds &l, int i, int n, int site) {
+__device__ __forceinline__ int chk_(const Lds &l, int i, int n, int site) {
     if ((unsigned)i < (unsigned)n) return i;
     atomicCAS(l.status, 0, -100 - site);
     return 0;
 }
+#define chk(l, i, n, site) chk_(l, i, (l).n, site)
 #else
-__device__ __forceinline__ int chk(const Lds &, int i, int, int) { return i; }
+#define chk(l, i, n, site) (i)
 #endif
-__device__ __forceinline__ uint8_t &Gc(const Lds &l, int i) { return smem[l.g + chk(l, i, l.nS2, 1)]; }
-__device__ __forceinline__ int16_t &AR(const Lds &l, int i) { return reinterpret_cast<int16_t *>(smem + l.ar)[chk(l, i, l.nN, 2)]; }
-__device__ __forceinline__ int16_t &AC(const Lds &l, int i) { return reinterpret_cast<int16_t *>(smem + l.ac)[chk(l, i, l.nN, 3)]; }
-__device__ __forceinline__ int16_t &PR(const Lds &l, int i) { return reinterpret_cast<int16_t *>(smem + l.pr)[chk(l, i, l.nM, 4)]; }
-__device__ __forceinline__ int16_t &PC(const Lds &l, int i) { return reinterpret_cast<int16_t *>(smem + l.pc)[chk(l, i, l.nM, 5)]; }
-__device__ __forceinline__ uint8_t &ACT(const Lds &l, int i) { return smem[l.act + chk(l, i, l.nN, 6)]; }
-__device__ __forceinline__ uint8_t &ALV(const Lds &l, int i) { return smem[l.alive + chk(l, i, l.nM, 7)]; }
-__device__ __forceinline__ uint8_t &PCNT(const Lds &l, int i) { return smem[l.pcnt + chk(l, i, l.nM, 8)]; }
-__device__ __forceinline__ uint8_t &PMV(const Lds &l, int i) { return smem[l.pmv + chk(l, i, l.nM, 9)]; }
-__device__ __forceinline__ uint32_t &VIS(const Lds &l, int i) { return reinterpret_cast<uint32_t *>(smem + l.vis)[chk(l, i, l.nS, 10)]; }
+__device__ __forceinline__ uint8_t &Gc(const Lds l, int i) { return smem[l.g + chk(l, i, nS2, 1)]; }
+__device__ __forceinline__ int16_t &AR(const Lds l, int i) { return reinterpret_cast<int16_t *>(smem + l.ar)[chk(l, i, nN, 2)]; }
+__device__ __forceinline__ int16_t &AC(const Lds l, int i) { return reinterpret_cast<int16_t *>(smem + l.ac)[chk(l, i, nN, 3)]; }
+__device__ __forceinline__ int16_t &PR(const Lds l, int i) { return reinterpret_cast<int16_t *>(smem + l.pr)[chk(l, i, nM, 4)]; }
+__device__ __forceinline__ int16_t &PC(const Lds l, int i) { return reinterpret_cast<int16_t *>(smem + l.pc)[chk(l, i, nM, 5)]; }
+__device__ __forceinline__ uint8_t &ACT(const Lds l, int i) { return smem[l.act + chk(l, i, nN, 6)]; }
+__device__ __forceinline__ uint8_t &ALV(const Lds l, int i) { return smem[l.alive + chk(l, i, nM, 7)]; }
+__device__ __forceinline__ uint8_t &PCNT(const Lds l, int i) { return smem[l.pcnt + chk(l, i, nM, 8)]; }
+__device__ __forceinline__ uint8_t &PMV(const Lds l, int i) { return smem[l.pmv + chk(l, i, nM, 9)]; }
+__device__ __forceinline__ uint32_t &VIS(const Lds l, int i) { return reinterpret_cast<uint32_t *>(smem + l.vis)[chk(l, i, nS, 10)]; }
 
-__device__ __forceinline__ int cell(const Lds &l, int r, int c, int S) { return in_grid(r, c, S) ? (int)Gc(l, r * S + c) : -1; }
+__device__ __forceinline__ int cell(const Lds l, int r, int c, int S) { return in_grid(r, c, S) ? (int)Gc(l, r * S + c) : -1; }
 // _neighbour_agents / _neighbour_preys count (predator_prey.py:309-351): D,U,R,L, each bounds-checked
-__device__ __forceinline__ int count_adj(const Lds &l, int r, int c, int S, int kind) {
+__device__ __forceinline__ int count_adj(const Lds l, int r, int c, int S, int kind) {
     return (cell(l, r + 1, c, S) == kind) + (cell(l, r - 1, c, S) == kind) + (cell(l, r, c + 1, S) == kind) +
            (cell(l, r, c - 1, S) == kind);
 }
@@ -119,29 +129,59 @@ __device__ __forceinline__ void uniform4(const Rng &rng, uint32_t site, uint32_t
 }
 
 // ---------------------------------------------------------------------------------------
-// reset: rejection-sampled spawn (predator_prey.py:150-171,206-232; coverage.py:172-196,221-246)
-// Wave-uniform loop: every lane evaluates the same candidate, lane 0 commits it.
+// Sub-wave groups: LPE lanes per env (16 / 32 / 64), G = 64 / LPE envs per wave.  All G envs of a
+// wave run the same program in lockstep; "group-uniform" values are identical within a group.
 // ---------------------------------------------------------------------------------------
-template <int SCEN>
-__device__ __forceinline__ void do_reset(const EnvDev &p, const Lds l, const Rng rng, const cm_rng_tape &tape, int b, int lane) {
-    const int S = p.S, N = p.N, M = p.M;
-    // fresh tile
-    for (int k = lane; k < S * S; k += WAVE) Gc(l, k) = (SCEN == CM_CO) ? p.base_grid[k] : (uint8_t)C_EMPTY;
-    if (SCEN == CM_CO) for (int r = lane; r < S; r += WAVE) VIS(l, r) = 0u;
+template <int LPE>
+struct Grp {
+    int sub, sl;                 // group index inside the wave, lane inside the group
+    __device__ __forceinline__ unsigned long long mask() const {
+        return LPE == 64 ? ~0ull : (((1ull << (LPE & 63)) - 1ull) << (sub * LPE));
+    }
+    __device__ __forceinline__ bool any(bool pred) const { return (__ballot(pred) & mask()) != 0ull; }
+    __device__ __forceinline__ int count(bool pred) const { return __popcll(__ballot(pred) & mask()); }
+};
+
+// floor(k / d) for 0 <= k < 2^22, d >= 1, with a precomputed float reciprocal (instead of the ~35
+// instruction integer division): the float product is off by at most one, fixed up exactly.
+__device__ __forceinline__ int fdiv(int k, int d, float rcp) {
+    int q = (int)((float)k * rcp);
+    int r = k - q * d;
+    if (r >= d) { ++q; } else if (r < 0) { --q; }
+    return q;
+}
+
+// ---------------------------------------------------------------------------------------
+// reset: rejection-sampled spawn (predator_prey.py:150-171,206-232; coverage.py:172-196,221-246).
+// Every lane of a group evaluates the same candidate, lane 0 of the group commits it; groups that do
+// not reset (need == false) idle through the loop.
+// ---------------------------------------------------------------------------------------
+template <int SCEN, int LPE>
+__device__ __forceinline__ void do_reset(const EnvDev &p, const Lds l, const Rng rng, const cm_rng_tape &tape, int b,
+                                         const Grp<LPE> g, bool need) {
+    const int S = p.S, N = p.N, M = p.M, sl = g.sl;
+    if (need) {
+        for (int k = sl; k < S * S; k += LPE) Gc(l, k) = (SCEN == CM_CO) ? p.base_grid[k] : (uint8_t)C_EMPTY;
+        if (SCEN == CM_CO) for (int r = sl; r < S; r += LPE) VIS(l, r) = 0u;
+    }
     __syncthreads();
     const int lo = (SCEN == CM_CO) ? 1 : 0;                              // randint(1, m) vs randint(0, G-1)
-    int cursor = 0;
-    bool fail = false;
     const int total = N + M;
-    for (int e = 0; e < total && !fail; ++e) {
+    int e = need ? 0 : total, cursor = 0;
+    bool fail = false;
+    while (__any(e < total)) {
+        const bool act = e < total;
         const bool is_prey = e >= N;
-        for (;;) {
-            int r, c;
+        int r = 0, c = 0;
+        bool ok = false;
+        if (act) {
             if (p.rng_mode == CM_RNG_TAPE) {
-                if (cursor >= tape.spawn_cap) { fail = true; break; }
-                const int32_t *t = tape.spawn + ((size_t)b * tape.spawn_cap + cursor) * 2;
-                r = t[0]; c = t[1];
-                if (r < 0) { fail = true; break; }
+                if (cursor >= tape.spawn_cap) { fail = true; }
+                else {
+                    const int32_t *t = tape.spawn + ((size_t)b * tape.spawn_cap + cursor) * 2;
+                    r = t[0]; c = t[1];
+                    if (r < 0) fail = true;
+                }
             } else {
                 const u32x4 x = rng.at(SITE_SPAWN, (uint32_t)cursor);
                 const uint32_t sp = (uint32_t)((SCEN == CM_CO) ? S - 2 : S);
@@ -149,49 +189,52 @@ __device__ __forceinline__ void do_reset(const EnvDev &p, const Lds l, const Rng
                 c = lo + (int)__umulhi(x.y, sp);
             }
             ++cursor;
-            bool ok = in_grid(r, c, S) && Gc(l, r * S + c) == C_EMPTY;          // _is_cell_vacant
-            if (ok && is_prey) ok = count_adj(l, r, c, S, C_AGENT) == 0;    // predator_prey.py:166
-            if (ok) {
-                if (lane == 0) {
-                    if (!is_prey) { AR(l, e) = (int16_t)r; AC(l, e) = (int16_t)c; Gc(l, r * S + c) = C_AGENT;
-                                    if (SCEN == CM_CO) VIS(l, r) |= (1u << c); }      // coverage.py:187
-                    else { PR(l, e - N) = (int16_t)r; PC(l, e - N) = (int16_t)c; Gc(l, r * S + c) = C_PREY; }
-                }
-                __syncthreads();
-                break;
+            if (!fail) {
+                ok = in_grid(r, c, S) && Gc(l, r * S + c) == C_EMPTY;            // _is_cell_vacant
+                if (ok && is_prey) ok = count_adj(l, r, c, S, C_AGENT) == 0;      // predator_prey.py:166
             }
         }
+        __syncthreads();                                   // all probes done before anybody commits
+        if (ok && sl == 0) {
+            if (!is_prey) { AR(l, e) = (int16_t)r; AC(l, e) = (int16_t)c; Gc(l, r * S + c) = C_AGENT;
+                            if (SCEN == CM_CO) VIS(l, r) |= (1u << c); }          // coverage.py:187
+            else { PR(l, e - N) = (int16_t)r; PC(l, e - N) = (int16_t)c; Gc(l, r * S + c) = C_PREY; }
+        }
+        __syncthreads();
+        if (ok) ++e;
+        if (fail) e = total;
     }
-    if (fail && lane == 0) raise(p, CM_ERR_TAPE);
-    for (int j = lane; j < M; j += WAVE) ALV(l, j) = 1;
+    if (fail && sl == 0) raise(p, CM_ERR_TAPE);
+    if (need) for (int j = sl; j < M; j += LPE) ALV(l, j) = 1;
     __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------
 // emission: obs + dist_adj + channels + state write-back
 // ---------------------------------------------------------------------------------------
-template <int SCEN>
-__device__ __forceinline__ void emit(const EnvDev &p, const Lds l, const Rng rng, const cm_rng_tape &tape, const cm_step_out &out,
-                     int b, int lane, int step_count, int slot) {
-    const int S = p.S, N = p.N, M = p.M, R = p.R, W = p.W, d = p.d, WW = W * W;
-    // ---- observations [N*d], lanes stride the flattened row -> coalesced 256-B stores ----
+template <int SCEN, int LPE>
+__device__ __forceinline__ void emit(const EnvDev &p, const Lds l, const Rng rng, const cm_rng_tape &tape,
+                                     const cm_step_out &out, int b, const Grp<LPE> g, int step_count, int slot) {
+    const int S = p.S, N = p.N, M = p.M, R = p.R, W = p.W, d = p.d, WW = W * W, sl = g.sl;
+    const float rcp_d = p.rcp_d, rcp_W = p.rcp_W, rcp_N = p.rcp_N, rcp_WW = p.rcp_WW, rcp_NN = p.rcp_NN;
+    // ---- observations [N*d], lanes stride the flattened row -> coalesced stores ----
     if (out.obs) {
         float *o = out.obs + (size_t)b * N * d;
         const int total = N * d;
-        for (int k = lane; k < total; k += WAVE) {
-            const int i = k / d, f = k - i * d;
+        for (int k = sl; k < total; k += LPE) {
+            const int i = fdiv(k, d, rcp_d), f = k - i * d;
             const int r0 = AR(l, i), c0 = AC(l, i);
             float v;
             if (SCEN == CM_PP) {
                 if (f < 2 * WW) {                                   // get_neighbors (predator_prey.py:173-181)
-                    const int chn = f >= WW, w = f - chn * WW, wr = w / W, wc = w - wr * W;
+                    const int chn = f >= WW, w = f - chn * WW, wr = fdiv(w, W, rcp_W), wc = w - wr * W;
                     v = (cell(l, r0 - R + wr, c0 - R + wc, S) == (chn ? C_PREY : C_AGENT)) ? 1.0f : 0.0f;
                 } else if (f == 2 * WW) v = p.lut_row[r0];          // row / G          (:195)
                 else if (f == 2 * WW + 1) v = p.lut_col[c0];        // col / (G-1)      (:195)
                 else v = p.lut_step[step_count];                    // step / Tmax      (:196)
             } else {
                 if (f < 3 * WW) {                                   // get_local_view (coverage.py:448-480)
-                    const int chn = f / WW, w = f - chn * WW, wr = w / W, wc = w - wr * W;
+                    const int chn = fdiv(f, WW, rcp_WW), w = f - chn * WW, wr = fdiv(w, W, rcp_W), wc = w - wr * W;
                     const int rr = r0 - R + wr, cc = c0 - R + wc;
                     const bool in = in_grid(rr, cc, S);
                     if (chn == 0) v = (!in || Gc(l, rr * S + cc) == C_WALL) ? 1.0f : 0.0f;
@@ -207,8 +250,8 @@ __device__ __forceinline__ void emit(const EnvDev &p, const Lds l, const Rng rng
     // ---- range adjacency (env_communication.py:218-243): integer form of cdist <= Rcom_th ----
     if (out.dist_adj && !p.adj_const) {
         float *a = out.dist_adj + (size_t)b * N * N;
-        for (int k = lane; k < N * N; k += WAVE) {
-            const int i = k / N, j = k - i * N;
+        for (int k = sl; k < N * N; k += LPE) {
+            const int i = fdiv(k, N, rcp_N), j = k - i * N;
             const int dr = AR(l, i) - AR(l, j), dc = AC(l, i) - AC(l, j);
             a[k] = (dr * dr + dc * dc <= p.rc2) ? 1.0f : 0.0f;
         }
@@ -220,19 +263,19 @@ __device__ __forceinline__ void emit(const EnvDev &p, const Lds l, const Rng rng
         const int total = L * NN;
         if (p.rng_mode == CM_RNG_TAPE) {
             const float *u = tape.iid_u + ((size_t)b * 2 + slot) * total;
-            for (int k = lane; k < total; k += WAVE) {
-                const int ij = k % NN, i = ij / N, j = ij - i * N;
+            for (int k = sl; k < total; k += LPE) {
+                const int ij = k - fdiv(k, NN, rcp_NN) * NN, i = fdiv(ij, N, rcp_N), j = ij - i * N;
                 ch[k] = ((u[k] + (i == j ? 1.0f : 0.0f)) >= p.ploss) ? 1.0f : 0.0f;
             }
         } else {
             const uint32_t site = slot ? SITE_IID_RESET : SITE_IID_STEP;
-            for (int q = lane; q * 4 < total; q += WAVE) {
+            for (int q = sl; q * 4 < total; q += LPE) {
                 const u32x4 x = rng.at(site, (uint32_t)q);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int k = q * 4 + e;
                     if (k < total) {
-                        const int ij = k % NN, i = ij / N, j = ij - i * N;
+                        const int ij = k - fdiv(k, NN, rcp_NN) * NN, i = fdiv(ij, N, rcp_N), j = ij - i * N;
                         ch[k] = ((unit_f32(pick(x, e)) + (i == j ? 1.0f : 0.0f)) >= p.ploss) ? 1.0f : 0.0f;
                     }
                 }
@@ -243,7 +286,7 @@ __device__ __forceinline__ void emit(const EnvDev &p, const Lds l, const Rng rng
         uint8_t *gs = p.ge_state + (size_t)b * NN;
         const uint32_t site = slot ? SITE_GE_RESET : SITE_GE_STEP;
         const int l0 = slot ? 1 : 0;                                 // reset: hop 0 = all good, then L-1 transitions
-        for (int k0 = lane * 4; k0 < NN; k0 += WAVE * 4) {
+        for (int k0 = sl * 4; k0 < NN; k0 += LPE * 4) {
             uint8_t s[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) s[e] = (k0 + e < NN) ? (slot ? (uint8_t)1 : gs[k0 + e]) : (uint8_t)0;
@@ -262,7 +305,7 @@ __device__ __forceinline__ void emit(const EnvDev &p, const Lds l, const Rng rng
                 for (int e = 0; e < 4; ++e) {
                     const int k = k0 + e;
                     if (k >= NN) continue;
-                    const int i = k / N, j = k - i * N;
+                    const int i = fdiv(k, N, rcp_N), j = k - i * N;
                     const float eye = (i == j) ? 1.0f : 0.0f;
                     const bool e_gb = (ugb[e] + eye) < p.pgb, e_bg = (ubg[e] + eye) < p.pbg;
                     const bool g_next = s[e] && !(s[e] && e_gb), b_next = (!s[e]) && e_bg;
@@ -274,87 +317,96 @@ __device__ __forceinline__ void emit(const EnvDev &p, const Lds l, const Rng rng
         }
     }
     // ---- state write-back ----
-    for (int i = lane; i < N; i += WAVE) p.agent_pos[(size_t)b * N + i] = make_int2(AR(l, i), AC(l, i));
+    for (int i = sl; i < N; i += LPE) p.agent_pos[(size_t)b * N + i] = make_int2(AR(l, i), AC(l, i));
     if (SCEN == CM_PP) {
-        for (int j = lane; j < M; j += WAVE) {
+        for (int j = sl; j < M; j += LPE) {
             p.prey_pos[(size_t)b * M + j] = make_int2(PR(l, j), PC(l, j));
             p.alive[(size_t)b * M + j] = ALV(l, j);
         }
     } else {
-        for (int r = lane; r < S; r += WAVE) p.visited[(size_t)b * S + r] = VIS(l, r);
+        for (int r = sl; r < S; r += LPE) p.visited[(size_t)b * S + r] = VIS(l, r);
     }
 }
 
 // ---------------------------------------------------------------------------------------
 // the step kernel
 // ---------------------------------------------------------------------------------------
-template <int SCEN>
+template <int SCEN, int LPE>
 __global__ __launch_bounds__(WAVE) void env_kernel(EnvDev p, const int32_t *__restrict__ actions, cm_rng_tape tape,
                                                   cm_step_out out, int reset_only) {
-    Lds l;
-    lds_layout(p.S, p.N, p.M, &l);
-    l.status = p.status;
-    const int b = blockIdx.x, lane = threadIdx.x;
+    constexpr int G = WAVE / LPE;
+    Grp<LPE> g;
+    g.sub = threadIdx.x / LPE; g.sl = threadIdx.x % LPE;
+    const int sl = g.sl;
+    const int b_raw = blockIdx.x * G + g.sub;
+    const bool valid = b_raw < p.B;
+    const int b = valid ? b_raw : p.B - 1;            // idle groups shadow the last env and never commit
+    const Lds l = make_lds(p.S, p.N, p.M, p.lds_env * g.sub, p.status);
     const int S = p.S, N = p.N, M = p.M;
     Rng rng{ (uint32_t)(p.env_id_offset + b), p.rng_step[b], p.key0, p.key1 };
+    cm_step_out o = out;
+    if (!valid) { o.obs = nullptr; o.dist_adj = nullptr; o.channels = nullptr; }
 
     if (reset_only) {
-        do_reset<SCEN>(p, l, rng, tape, b, lane);
-        if (lane == 0) { p.step_count[b] = 0; if (SCEN == CM_CO) p.total_capture[b] = 0; p.rng_step[b] = rng.step + 1; }
-        emit<SCEN>(p, l, rng, tape, out, b, lane, 0, 1);
+        do_reset<SCEN, LPE>(p, l, rng, tape, b, g, true);
+        if (!valid) return;
+        if (sl == 0) { p.step_count[b] = 0; if (SCEN == CM_CO) p.total_capture[b] = 0; p.rng_step[b] = rng.step + 1; }
+        emit<SCEN, LPE>(p, l, rng, tape, o, b, g, 0, 1);
         return;
     }
 
     // ---- load SoA state, rebuild the occupancy tile in LDS ----
     bool bad_action = false;
-    for (int i = lane; i < N; i += WAVE) {
+    for (int i = sl; i < N; i += LPE) {
         const int2 q = p.agent_pos[(size_t)b * N + i];
         AR(l, i) = (int16_t)q.x; AC(l, i) = (int16_t)q.y;
         const int a = actions[(size_t)b * N + i];
-        bad_action |= (unsigned)a > 4u;
-        ACT(l, i) = (uint8_t)(a & 7);
+        const bool bad = (unsigned)a > 4u;
+        bad_action |= bad;
+        ACT(l, i) = (uint8_t)(bad ? 4 : a);
     }
     if (SCEN == CM_PP)
-        for (int j = lane; j < M; j += WAVE) {
+        for (int j = sl; j < M; j += LPE) {
             const int2 q = p.prey_pos[(size_t)b * M + j];
             PR(l, j) = (int16_t)q.x; PC(l, j) = (int16_t)q.y;
             ALV(l, j) = p.alive[(size_t)b * M + j];
         }
-    for (int k = lane; k < S * S; k += WAVE) Gc(l, k) = (SCEN == CM_CO) ? p.base_grid[k] : (uint8_t)C_EMPTY;
-    if (SCEN == CM_CO) for (int r = lane; r < S; r += WAVE) VIS(l, r) = p.visited[(size_t)b * S + r];
-    if (__any(bad_action)) {               // the reference raises (predator_prey.py:255); flag and leave state untouched
-        if (lane == 0) raise(p, CM_ERR_ACTION);
-        return;
-    }
+    for (int k = sl; k < S * S; k += LPE) Gc(l, k) = (SCEN == CM_CO) ? p.base_grid[k] : (uint8_t)C_EMPTY;
+    if (SCEN == CM_CO) for (int r = sl; r < S; r += LPE) VIS(l, r) = p.visited[(size_t)b * S + r];
+    // the reference raises on a bad action (predator_prey.py:255): flag it; the env is left untouched
+    const bool env_bad = g.any(bad_action);
+    if (env_bad && sl == 0 && valid) raise(p, CM_ERR_ACTION);
+    const bool commit = valid && !env_bad;
     __syncthreads();
-    for (int i = lane; i < N; i += WAVE) Gc(l, AR(l, i) * S + AC(l, i)) = C_AGENT;
+    for (int i = sl; i < N; i += LPE) Gc(l, AR(l, i) * S + AC(l, i)) = C_AGENT;
     if (SCEN == CM_PP)
-        for (int j = lane; j < M; j += WAVE) if (ALV(l, j)) Gc(l, PR(l, j) * S + PC(l, j)) = C_PREY;
+        for (int j = sl; j < M; j += LPE) if (ALV(l, j)) Gc(l, PR(l, j) * S + PC(l, j)) = C_PREY;
     __syncthreads();
 
     int step_count = p.step_count[b] + 1;
     int succ = p.success[b];
     int done = 0;
     double reward;
-    int det[6] = { 0, 0, 0, 0, 0, 0 };
+    int det0 = 0, det1 = 0, det2 = 0, det3 = 0, det4 = 0, det5 = 0;
 
     if (SCEN == CM_PP) {
-        // ---- agents move in index order (predator_prey.py:497-500, :240-261) : wave-uniform ----
+        // ---- agents move in index order (predator_prey.py:497-500, :240-261): group-uniform loop ----
         int moving = 0;
         for (int i = 0; i < N; ++i) {
             const int a = ACT(l, i);
+            bool mv = false;
+            int r = 0, c = 0, nr = 0, nc = 0;
             if (a != 4) {
                 ++moving;
-                const int r = AR(l, i), c = AC(l, i), nr = r + dr_of(a), nc = c + dc_of(a);
-                if (in_grid(nr, nc, S) && Gc(l, nr * S + nc) == C_EMPTY) {
-                    if (lane == 0) { Gc(l, r * S + c) = C_EMPTY; Gc(l, nr * S + nc) = C_AGENT; AR(l, i) = (int16_t)nr; AC(l, i) = (int16_t)nc; }
-                    __syncthreads();
-                }
+                r = AR(l, i); c = AC(l, i); nr = r + dr_of(a); nc = c + dc_of(a);
+                mv = in_grid(nr, nc, S) && Gc(l, nr * S + nc) == C_EMPTY;
             }
+            __syncthreads();
+            if (mv && sl == 0) { Gc(l, r * S + c) = C_EMPTY; Gc(l, nr * S + nc) = C_AGENT; AR(l, i) = (int16_t)nr; AC(l, i) = (int16_t)nc; }
+            __syncthreads();
         }
-        __syncthreads();
         // ---- per-prey work that only depends on the (now static) agent layer: one lane per prey ----
-        for (int j = lane; j < M; j += WAVE) {
+        for (int j = sl; j < M; j += LPE) {
             int cnt = 0, mv = 4;
             if (ALV(l, j)) {
                 const int r = PR(l, j), c = PC(l, j);
@@ -381,53 +433,56 @@ __global__ __launch_bounds__(WAVE) void env_kernel(EnvDev p, const int32_t *__re
         }
         // prey_watching (:419-423): agents 4-adjacent to a live prey (prey layer still at start-of-phase positions)
         int wsum = 0;
-        for (int i0 = 0; i0 < N; i0 += WAVE) {
-            const int i = i0 + lane;
+        for (int i0 = 0; i0 < N; i0 += LPE) {
+            const int i = i0 + sl;
             const bool w = i < N && count_adj(l, AR(l, i), AC(l, i), S, C_PREY) > 0;
-            wsum += __popcll(__ballot(w));
+            wsum += g.count(w);
         }
         __syncthreads();
-        // ---- captures + prey moves in index order (:416-432 / :460-478, :276-301) : wave-uniform ----
+        // ---- captures + prey moves in index order (:416-432 / :460-478, :276-301): group-uniform loop ----
         int capture = 0, penalty = 0;
         bool tape_short = false;
         for (int j = 0; j < M; ++j) {
-            if (!ALV(l, j)) continue;
-            const int r = PR(l, j), c = PC(l, j), cnt = PCNT(l, j), mvb = PMV(l, j);
-            bool captured = false;
-            if (cnt >= 1) {
-                int need = p.load;
-                if (p.load != 2) {                                       // reward_individual :467-470
-                    const bool on_r = (r == 0 || r == S - 1), on_c = (c == 0 || c == S - 1);
-                    const int adj = (on_r && on_c) ? 2 : ((on_r || on_c) ? 3 : p.load);   // __create_edges :123-144
-                    const int avail = adj - count_adj(l, r, c, S, C_PREY);
-                    need = p.load < avail ? p.load : avail;
+            const bool alive = ALV(l, j) != 0;
+            bool captured = false, moved = false;
+            int r = 0, c = 0, nr = 0, nc = 0;
+            if (alive) {
+                r = PR(l, j); c = PC(l, j);
+                const int cnt = PCNT(l, j), mvb = PMV(l, j);
+                if (cnt >= 1) {
+                    int need = p.load;
+                    if (p.load != 2) {                                       // reward_individual :467-470
+                        const bool on_r = (r == 0 || r == S - 1), on_c = (c == 0 || c == S - 1);
+                        const int adj = (on_r && on_c) ? 2 : ((on_r || on_c) ? 3 : p.load);   // __create_edges :123-144
+                        const int avail = adj - count_adj(l, r, c, S, C_PREY);
+                        need = p.load < avail ? p.load : avail;
+                    }
+                    if (need <= cnt) { captured = true; ++capture; } else ++penalty;
                 }
-                if (need <= cnt) { captured = true; ++capture; } else ++penalty;
-            }
-            if (captured) {
-                if (lane == 0) { ALV(l, j) = 0; Gc(l, r * S + c) = C_EMPTY; }      // :301
-                __syncthreads();
-            } else {
-                if (mvb & 8) tape_short = true;
-                const int mv = mvb & 7;
-                if (mv != 4) {
-                    const int nr = r + dr_of(mv), nc = c + dc_of(mv);
-                    if (in_grid(nr, nc, S) && Gc(l, nr * S + nc) == C_EMPTY) {
-                        if (lane == 0) { Gc(l, r * S + c) = C_EMPTY; Gc(l, nr * S + nc) = C_PREY; PR(l, j) = (int16_t)nr; PC(l, j) = (int16_t)nc; }
-                        __syncthreads();
+                if (!captured) {
+                    if (mvb & 8) tape_short = true;
+                    const int mv = mvb & 7;
+                    if (mv != 4) {
+                        nr = r + dr_of(mv); nc = c + dc_of(mv);
+                        moved = in_grid(nr, nc, S) && Gc(l, nr * S + nc) == C_EMPTY;
                     }
                 }
             }
+            __syncthreads();
+            if (sl == 0) {
+                if (captured) { ALV(l, j) = 0; Gc(l, r * S + c) = C_EMPTY; }      // :301
+                else if (moved) { Gc(l, r * S + c) = C_EMPTY; Gc(l, nr * S + nc) = C_PREY; PR(l, j) = (int16_t)nr; PC(l, j) = (int16_t)nc; }
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        if (tape_short && lane == 0) raise(p, CM_ERR_TAPE_PREY);
+        if (tape_short && sl == 0 && commit) raise(p, CM_ERR_TAPE_PREY);
         // reward in f64 exactly as the Python expression evaluates (:434 / :480); no FMA contraction (build flag)
         reward = (p.step_cost + p.cap_rew * (double)capture) + (p.move_cost * (double)moving) / (double)N;
         if (p.load == 2) reward = reward + p.penalty * (double)penalty;
-        det[0] = capture; det[1] = moving; det[2] = penalty; det[4] = wsum;
+        det0 = capture; det1 = moving; det2 = penalty; det4 = wsum;
         bool any_alive = false;
-        for (int j0 = 0; j0 < M; j0 += WAVE) any_alive |= __any(j0 + lane < M && ALV(l, j0 + lane));
-        if (out.prey_alive) for (int j = lane; j < M; j += WAVE) out.prey_alive[(size_t)b * M + j] = ALV(l, j);
+        for (int j0 = 0; j0 < M; j0 += LPE) any_alive |= g.any(j0 + sl < M && ALV(l, j0 + sl));
+        if (o.prey_alive && commit) for (int j = sl; j < M; j += LPE) o.prey_alive[(size_t)b * M + j] = ALV(l, j);
         done = (step_count >= p.max_steps) || !any_alive;               // :511-517
         if (done) succ = any_alive ? 0 : 1;
     } else {
@@ -435,25 +490,28 @@ __global__ __launch_bounds__(WAVE) void env_kernel(EnvDev p, const int32_t *__re
         int cap = 0, mov = 0, pen = 0, lazy = 0, rev = 0;
         for (int i = 0; i < N; ++i) {
             const int a = ACT(l, i);
-            if (a == 4) { ++lazy; continue; }
-            ++mov;
-            const int r = AR(l, i), c = AC(l, i), nr = r + dr_of(a), nc = c + dc_of(a);
-            if (in_grid(nr, nc, S) && Gc(l, nr * S + nc) == C_EMPTY) {
-                const bool seen = (VIS(l, nr) >> nc) & 1u;
-                if (seen) ++rev; else ++cap;
-                if (lane == 0) {
-                    VIS(l, nr) |= (1u << nc);
-                    Gc(l, r * S + c) = C_EMPTY; Gc(l, nr * S + nc) = C_AGENT; AR(l, i) = (int16_t)nr; AC(l, i) = (int16_t)nc;
-                }
-                __syncthreads();
-            } else ++pen;
+            bool mv = false, seen = false;
+            int r = 0, c = 0, nr = 0, nc = 0;
+            if (a == 4) ++lazy;
+            else {
+                ++mov;
+                r = AR(l, i); c = AC(l, i); nr = r + dr_of(a); nc = c + dc_of(a);
+                mv = in_grid(nr, nc, S) && Gc(l, nr * S + nc) == C_EMPTY;
+                if (mv) { seen = (VIS(l, nr) >> nc) & 1u; if (seen) ++rev; else ++cap; }
+                else ++pen;
+            }
+            __syncthreads();
+            if (mv && sl == 0) {
+                VIS(l, nr) |= (1u << nc);
+                Gc(l, r * S + c) = C_EMPTY; Gc(l, nr * S + nc) = C_AGENT; AR(l, i) = (int16_t)nr; AC(l, i) = (int16_t)nc;
+            }
+            __syncthreads();
         }
-        __syncthreads();
         const int total = p.total_capture[b] + cap;
         double fin = 0.0;
         if (total == p.n_empty) { fin = p.final_reward; done = 1; }     // :381-385
         if (step_count >= p.max_steps) { succ = done ? 1 : 0; done = 1; }   // :388-393
-        if (lane == 0) p.total_capture[b] = total;
+        if (sl == 0 && commit) p.total_capture[b] = total;
         const double n = (double)N;                                      // get_reward (:299-317), left-to-right
         reward = p.step_cost + p.cap_rew * ((double)cap / n);
         reward = reward + p.move_cost * ((double)mov / n);
@@ -461,30 +519,33 @@ __global__ __launch_bounds__(WAVE) void env_kernel(EnvDev p, const int32_t *__re
         reward = reward + p.lazy * ((double)lazy / n);
         reward = reward + p.revisit * ((double)rev / n);
         reward = reward + fin;
-        det[0] = cap; det[1] = mov; det[2] = pen; det[3] = lazy; det[4] = rev; det[5] = fin != 0.0;
+        det0 = cap; det1 = mov; det2 = pen; det3 = lazy; det4 = rev; det5 = fin != 0.0;
     }
 
     if (step_count >= p.mpl) done = 1;                                   // vec_env_executor.py:33-34
-    if (lane == 0) {
-        if (out.reward) out.reward[b] = (float)reward;
-        if (out.reward_f64) out.reward_f64[b] = reward;
-        if (out.done) out.done[b] = (uint8_t)done;
-        if (out.path_len) out.path_len[b] = done ? step_count : 0;
-        if (out.details) for (int k = 0; k < 6; ++k) out.details[(size_t)b * 6 + k] = det[k];
+    if (sl == 0 && commit) {
+        if (o.reward) o.reward[b] = (float)reward;
+        if (o.reward_f64) o.reward_f64[b] = reward;
+        if (o.done) o.done[b] = (uint8_t)done;
+        if (o.path_len) o.path_len[b] = done ? step_count : 0;
+        if (o.details) {
+            int32_t *dd = o.details + (size_t)b * 6;
+            dd[0] = det0; dd[1] = det1; dd[2] = det2; dd[3] = det3; dd[4] = det4; dd[5] = det5;
+        }
         p.rng_step[b] = rng.step + 1;
     }
     __syncthreads();
-    if (done) {                                                          // auto-reset (:36-43): emit the reset obs
-        do_reset<SCEN>(p, l, rng, tape, b, lane);
-        step_count = 0;
-        if (lane == 0 && SCEN == CM_CO) p.total_capture[b] = 0;
-    }
-    if (lane == 0) {
+    // auto-reset (:36-43): groups whose env finished re-spawn and emit the reset observation
+    do_reset<SCEN, LPE>(p, l, rng, tape, b, g, done != 0);
+    if (done) step_count = 0;
+    if (!commit) return;
+    if (sl == 0) {
+        if (done && SCEN == CM_CO) p.total_capture[b] = 0;
         p.step_count[b] = step_count;
         p.success[b] = succ;
-        if (out.success) out.success[b] = succ;
+        if (o.success) o.success[b] = succ;
     }
-    emit<SCEN>(p, l, rng, tape, out, b, lane, step_count, done ? 1 : 0);
+    emit<SCEN, LPE>(p, l, rng, tape, o, b, g, step_count, done ? 1 : 0);
 }
 
 __global__ void fill_const_kernel(float *adj, float *ch, int B, int N, int L, int channel) {
@@ -605,7 +666,18 @@ extern "C" int cm_env_create(const cm_env_cfg *cfg, cm_env_t *out) {
     hipMemcpy(base + o_lc, lut_col.data(), S * 4, hipMemcpyHostToDevice);
     hipMemcpy(base + o_ls, lut_step.data(), (c.max_steps + 1) * 4, hipMemcpyHostToDevice);
     if (c.channel == CM_CH_GE) hipMemset(base + o_ge, 1, B * N * N);
-    h->lds_bytes = lds_layout(S, c.n_agents, M ? M : 1, nullptr);
+    d.lds_env = lds_env_bytes(S, c.n_agents, M ? M : 1);
+    {   // lanes per env: the smallest sub-wave group that still gives every agent / prey its own lane
+        // measured (tools/envscale.py): at N <= 8 the step is dominated by the group-uniform serial loops, so
+        // four envs per wave win at every batch size; with more agents the emit loops dominate and a full
+        // wave per env has the lower latency until the batch is large enough to be throughput-bound.
+        const int big = c.n_agents > M ? c.n_agents : M;
+        d.lpe = big <= 8 ? 16 : ((big <= 32 && c.n_envs >= 8192) ? 32 : 64);
+        if (const char *e = getenv("COMMARL_ENV_LPE")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) d.lpe = v; }
+    }
+    h->lds_bytes = (size_t)d.lds_env * (WAVE / d.lpe);
+    d.rcp_d = 1.0f / (float)d.d; d.rcp_W = 1.0f / (float)d.W; d.rcp_N = 1.0f / (float)d.N;
+    d.rcp_WW = 1.0f / (float)(d.W * d.W); d.rcp_NN = 1.0f / (float)(d.N * d.N);
     e = hipDeviceSynchronize();
     if (e != hipSuccess) { hipFree(h->arena); delete h; return hip_fail(e, "cm_env_create sync"); }
     *out = h;
@@ -650,10 +722,13 @@ static int launch(cm_env_t h, const int32_t *actions, const cm_rng_tape *tape, c
     cm_rng_tape t{};
     if (tape) t = *tape;
     const EnvDev &d = h->dev;
-    if (d.scen == CM_PP)
-        hipLaunchKernelGGL(env_kernel<CM_PP>, dim3(d.B), dim3(WAVE), h->lds_bytes, (hipStream_t)stream, d, actions, t, *out, reset_only);
-    else
-        hipLaunchKernelGGL(env_kernel<CM_CO>, dim3(d.B), dim3(WAVE), h->lds_bytes, (hipStream_t)stream, d, actions, t, *out, reset_only);
+    const int G = WAVE / d.lpe;
+    const dim3 grid((d.B + G - 1) / G), block(WAVE);
+    const hipStream_t st = (hipStream_t)stream;
+#define CM_LAUNCH(SC, LP) hipLaunchKernelGGL((env_kernel<SC, LP>), grid, block, h->lds_bytes, st, d, actions, t, *out, reset_only)
+    if (d.scen == CM_PP) { if (d.lpe == 16) CM_LAUNCH(CM_PP, 16); else if (d.lpe == 32) CM_LAUNCH(CM_PP, 32); else CM_LAUNCH(CM_PP, 64); }
+    else { if (d.lpe == 16) CM_LAUNCH(CM_CO, 16); else if (d.lpe == 32) CM_LAUNCH(CM_CO, 32); else CM_LAUNCH(CM_CO, 64); }
+#undef CM_LAUNCH
     CM_HIP(hipGetLastError());
     return CM_OK;
 }

@@ -22,6 +22,8 @@ int hip_fail(hipError_t e, const char *what);      // -> CM_ERR_HIP
 struct EnvDev {
     int scen, B, N, M, S, R, W, d, load, max_steps, mpl, L, rc2, channel, add_clock, n_empty, rng_mode, env_id_offset;
     int adj_const, ch_const;
+    int lpe, lds_env;         // lanes per env (16/32/64) and LDS bytes per env
+    float rcp_d, rcp_W, rcp_N, rcp_WW, rcp_NN;   // float reciprocals for the exact fast division in the emit loops
     float ploss, pgb, pbg;
     double cap_rew, step_cost, move_cost, penalty, lazy, revisit, final_reward;
     uint32_t key0, key1;
