@@ -171,6 +171,181 @@ __global__ __launch_bounds__(TPB) void agg_bwd_kernel(int S, int N, int EPB, con
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// attention scores + softmax for the autograd path (attention_module.py:39-49):
+//   M[s,i,:] = softmax_j( Q[s,i,:] . E[s,j,:] )          Q = linear_in(E) comes from a torch GEMM
+// torch.matmul lowers this to a batched GEMM with N x N outputs (4 x 4 at config 2): three such GEMMs
+// (forward, dQ, dE) were 31 % of the PPO update.  Here a workgroup owns EPB whole samples, the Q / E
+// tiles are read from HBM once and everything else happens in LDS.
+// ---------------------------------------------------------------------------------------------
+template <int E>
+__global__ __launch_bounds__(TPB) void attn_fwd_kernel(int S, int N, int EPB, const float *__restrict__ q,
+                                                      const float *__restrict__ e, float *__restrict__ m) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int SE = E + 4;
+    const int tid = threadIdx.x, NN = N * N, NP = N | 1, rows_max = EPB * N;
+    float *Q = lds, *K = Q + (size_t)rows_max * SE, *M = K + (size_t)rows_max * SE;
+    for (int s0 = blockIdx.x * EPB; s0 < S; s0 += gridDim.x * EPB) {
+        const int envs = min(EPB, S - s0), rows = envs * N;
+        for (int k = tid; k < rows * (E / 4); k += TPB) {
+            const int r = k / (E / 4), c = k - r * (E / 4);
+            reinterpret_cast<float4 *>(Q + (size_t)r * SE)[c] = reinterpret_cast<const float4 *>(q + ((size_t)s0 * N + r) * E)[c];
+            reinterpret_cast<float4 *>(K + (size_t)r * SE)[c] = reinterpret_cast<const float4 *>(e + ((size_t)s0 * N + r) * E)[c];
+        }
+        __syncthreads();
+        for (int k = tid; k < envs * NN; k += TPB) {
+            const int en = k / NN, ij = k - en * NN, i = ij / N, j = ij - i * N;
+            const float4 *x = reinterpret_cast<const float4 *>(Q + (size_t)(en * N + i) * SE);
+            const float4 *y = reinterpret_cast<const float4 *>(K + (size_t)(en * N + j) * SE);
+            float acc = 0.0f;
+#pragma unroll
+            for (int c = 0; c < E / 4; ++c) {
+                const float4 u = x[c], v = y[c];
+                acc = fmaf(u.x, v.x, acc); acc = fmaf(u.y, v.y, acc); acc = fmaf(u.z, v.z, acc); acc = fmaf(u.w, v.w, acc);
+            }
+            M[(size_t)(en * N + i) * NP + j] = acc;
+        }
+        __syncthreads();
+        for (int r = tid; r < rows; r += TPB) {
+            float *mr = M + (size_t)r * NP;
+            float mx = -INFINITY, sum = 0.0f;
+            for (int j = 0; j < N; ++j) mx = fmaxf(mx, mr[j]);
+            for (int j = 0; j < N; ++j) { const float ex = expf(mr[j] - mx); mr[j] = ex; sum += ex; }
+            float *dst = m + ((size_t)s0 * N + r) * N;
+            for (int j = 0; j < N; ++j) dst[j] = mr[j] / sum;
+        }
+        __syncthreads();
+    }
+}
+
+// dS = M * (dM - sum_j dM*M) ; dQ = dS . E ; dE = dS^T . Q
+template <int E>
+__global__ __launch_bounds__(TPB) void attn_bwd_kernel(int S, int N, int EPB, const float *__restrict__ q,
+                                                      const float *__restrict__ e, const float *__restrict__ m,
+                                                      const float *__restrict__ d_m, float *__restrict__ d_q,
+                                                      float *__restrict__ d_e) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int SE = E + 4;
+    const int tid = threadIdx.x, NN = N * N, NP = N | 1, rows_max = EPB * N;
+    float *Q = lds, *K = Q + (size_t)rows_max * SE, *DS = K + (size_t)rows_max * SE;
+    for (int s0 = blockIdx.x * EPB; s0 < S; s0 += gridDim.x * EPB) {
+        const int envs = min(EPB, S - s0), rows = envs * N;
+        for (int k = tid; k < rows * (E / 4); k += TPB) {
+            const int r = k / (E / 4), c = k - r * (E / 4);
+            reinterpret_cast<float4 *>(Q + (size_t)r * SE)[c] = reinterpret_cast<const float4 *>(q + ((size_t)s0 * N + r) * E)[c];
+            reinterpret_cast<float4 *>(K + (size_t)r * SE)[c] = reinterpret_cast<const float4 *>(e + ((size_t)s0 * N + r) * E)[c];
+        }
+        for (int r = tid; r < rows; r += TPB) {
+            const float *mr = m + ((size_t)s0 * N + r) * N, *dr = d_m + ((size_t)s0 * N + r) * N;
+            float t = 0.0f;
+            for (int j = 0; j < N; ++j) t = fmaf(dr[j], mr[j], t);
+            for (int j = 0; j < N; ++j) DS[(size_t)r * NP + j] = mr[j] * (dr[j] - t);
+        }
+        __syncthreads();
+        const int o = tid % E, rg = tid / E;
+        for (int r0 = rg * RC; r0 < rows; r0 += (TPB / E) * RC) {
+            const int en = r0 / N;
+            float aq[RC] = { 0.f, 0.f, 0.f, 0.f }, ae[RC] = { 0.f, 0.f, 0.f, 0.f };
+            for (int j = 0; j < N; ++j) {
+                const float ev = K[(size_t)(en * N + j) * SE + o], qv = Q[(size_t)(en * N + j) * SE + o];
+#pragma unroll
+                for (int i = 0; i < RC; ++i) {
+                    const int r = min(r0 + i, rows - 1), li = r - en * N;
+                    if (li < N) {
+                        aq[i] = fmaf(DS[(size_t)r * NP + j], ev, aq[i]);                  // dQ[i] += dS[i][j] E[j]
+                        ae[i] = fmaf(DS[(size_t)(en * N + j) * NP + li], qv, ae[i]);      // dE[i] += dS[j][i] Q[j]
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < RC; ++i)
+                if (r0 + i < rows && (r0 + i) / N == en) {
+                    d_q[((size_t)s0 * N + r0 + i) * E + o] = aq[i];
+                    d_e[((size_t)s0 * N + r0 + i) * E + o] = ae[i];
+                }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight gradient of a per-agent dense layer over R = P*T*N rows (R ~ 1e6, P,Q <= 128):
+//   C[p][q] += sum_r A[r][p] * B[r][q]         ( nn.Linear: A = dY, B = X -> dW [out][in], db = colsum(dY);
+//                                                GCN H.W   : A = H,  B = dZ -> dW [in][out] )
+// rocBLAS/hipBLASLt run these "skinny" GEMMs (tiny output, million-deep reduction) at ~10 TFLOP/s; they
+// were 42 % of the PPO update.  Here a workgroup streams 64-row chunks of A and B through LDS and keeps
+// its share of the P x Q output in f32 MFMA accumulators; partial results are merged with float atomics.
+// ---------------------------------------------------------------------------------------------
+typedef float v4f __attribute__((ext_vector_type(4)));
+constexpr int WG_ROWS = 64;
+
+// coalesced [WG_ROWS x W] global -> LDS copy (float4 when the row is a power-of-two number of float4s)
+__device__ __forceinline__ void stage_rows(float *dst, int stride, const float *__restrict__ src, int W, long r0, int rows, int tid) {
+    const int w4 = W >> 2;
+    if ((W & 3) == 0 && (w4 & (w4 - 1)) == 0 && w4 <= TPB) {
+        const int x = tid & (w4 - 1), rstep = TPB / w4;
+        for (int r = tid / w4; r < WG_ROWS; r += rstep) {
+            const float4 v = r < rows ? reinterpret_cast<const float4 *>(src + (r0 + r) * W)[x] : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4 *>(dst + (size_t)r * stride + 4 * x) = v;
+        }
+    } else {
+        for (int k = tid; k < WG_ROWS * W; k += TPB) { const int r = k / W, x = k - r * W; dst[(size_t)r * stride + x] = r < rows ? src[(r0 + r) * W + x] : 0.0f; }
+    }
+}
+
+template <int MAXT>   // accumulator tiles per wave
+__global__ __launch_bounds__(TPB) void wgrad_kernel(long R, int P, int Q, const float *__restrict__ A, const float *__restrict__ B,
+                                                   float *__restrict__ C, float *__restrict__ colsum_a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
+    const int PT = (P + 15) >> 4, QT = (Q + 15) >> 4, NT = PT * QT;
+    const int SP = PT * 16 + 16, SQ = QT * 16 + 16;          // row strides == 16 (mod 32): conflict-free operand reads
+    float *As = lds, *Bs = As + (size_t)WG_ROWS * SP;
+    v4f acc[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) acc[t] = (v4f){ 0.f, 0.f, 0.f, 0.f };
+    float csum = 0.0f;
+    // zero the padding columns once (they feed MFMAs whose results are never stored)
+    for (int k = tid; k < WG_ROWS * SP; k += TPB) As[k] = 0.0f;
+    for (int k = tid; k < WG_ROWS * SQ; k += TPB) Bs[k] = 0.0f;
+    __syncthreads();
+    const long n_chunks = (R + WG_ROWS - 1) / WG_ROWS;
+    for (long ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+        const long r0 = ch * WG_ROWS;
+        const int rows = (int)min((long)WG_ROWS, R - r0);
+        stage_rows(As, SP, A, P, r0, rows, tid);
+        stage_rows(Bs, SQ, B, Q, r0, rows, tid);
+        __syncthreads();
+        if (colsum_a && tid < P) { float sacc = 0.0f; for (int r = 0; r < WG_ROWS; ++r) sacc += As[(size_t)r * SP + tid]; csum += sacc; }
+#pragma unroll 4
+        for (int kk = 0; kk < WG_ROWS / 4; ++kk) {
+            const float *ar = As + (size_t)(4 * kk + g) * SP + c, *br = Bs + (size_t)(4 * kk + g) * SQ + c;
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t) {
+                const int tile = wave + 4 * t;
+                if (tile < NT) {
+                    const int pt = tile / QT, qt = tile - pt * QT;
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[pt * 16], br[qt * 16], acc[t], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+        const int tile = wave + 4 * t;
+        if (tile < NT) {
+            const int pt = tile / QT, qt = tile - pt * QT, q = qt * 16 + c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int pp = pt * 16 + 4 * g + r;
+                if (pp < P && q < Q) atomicAdd(C + (size_t)pp * Q + q, acc[t][r]);
+            }
+        }
+    }
+    if (colsum_a && tid < P) atomicAdd(colsum_a + tid, csum);
+}
+
 __global__ void returns_kernel(int P, int T, const double *__restrict__ rewards, const int32_t *__restrict__ lens,
                                double gamma, float *__restrict__ returns) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -252,6 +427,64 @@ extern "C" int cm_masked_agg_backward(int32_t S, int32_t N, int32_t E, const flo
     const int epb = agg_epb(N);
     const int blocks = (int)std::min<long>((S + epb - 1) / epb, 256 * 4);
     hipLaunchKernelGGL(agg_bwd_kernel<64>, dim3(blocks), dim3(TPB), lds, (hipStream_t)stream, S, N, epb, attn, dist_adj, chan, (long)ch_stride, hw, out, d_out, d_attn, d_hw, d_bias);
+    CM_HIP(hipGetLastError());
+    return CM_OK;
+}
+
+extern "C" int cm_linear_wgrad(int64_t R, int32_t P, int32_t Q, const float *a, const float *b, float *c, float *colsum_a,
+                               void *stream) {
+    if (!a || !b || !c) return set_error(CM_ERR_ARG, "cm_linear_wgrad: null argument");
+    if (P < 1 || Q < 1 || P > 128 || Q > 128) return set_error(CM_ERR_ARG, "cm_linear_wgrad: 1 <= P, Q <= 128 required");
+    if (R <= 0) return CM_OK;
+    const int PT = (P + 15) / 16, QT = (Q + 15) / 16, NT = PT * QT;
+    const size_t lds = ((size_t)WG_ROWS * (PT * 16 + 16) + (size_t)WG_ROWS * (QT * 16 + 16)) * sizeof(float);
+    const long chunks = (R + WG_ROWS - 1) / WG_ROWS;
+    const int blocks = (int)std::min<long>(chunks, 512);
+    const hipStream_t st = (hipStream_t)stream;
+    const int per_wave = (NT + 3) / 4;
+    static bool once = false;
+    if (!once) {
+        CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        once = true;
+    }
+    if (per_wave <= 2) hipLaunchKernelGGL(wgrad_kernel<2>, dim3(blocks), dim3(TPB), lds, st, (long)R, P, Q, a, b, c, colsum_a);
+    else if (per_wave <= 8) hipLaunchKernelGGL(wgrad_kernel<8>, dim3(blocks), dim3(TPB), lds, st, (long)R, P, Q, a, b, c, colsum_a);
+    else hipLaunchKernelGGL(wgrad_kernel<16>, dim3(blocks), dim3(TPB), lds, st, (long)R, P, Q, a, b, c, colsum_a);
+    CM_HIP(hipGetLastError());
+    return CM_OK;
+}
+
+static size_t attn_lds(int N, int E) { const int epb = agg_epb(N), rows = epb * N; return ((size_t)rows * (E + 4) * 2 + (size_t)rows * (N | 1)) * 4; }
+
+extern "C" int cm_attention_forward(int32_t S, int32_t N, int32_t E, const float *q, const float *e, float *m, void *stream) {
+    if (!q || !e || !m) return set_error(CM_ERR_ARG, "cm_attention_forward: null argument");
+    if (E != 64) return set_error(CM_ERR_ARG, "cm_attention_forward: embedding dim 64 only");
+    if (S <= 0) return CM_OK;
+    const size_t lds = attn_lds(N, E);
+    if (lds > 160 * 1024) return set_error(CM_ERR_ARG, "cm_attention_forward: n_agents too large");
+    static bool once = false;
+    if (!once) { CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_fwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
+    const int epb = agg_epb(N);
+    const int blocks = (int)std::min<long>((S + epb - 1) / epb, 256 * 8);
+    hipLaunchKernelGGL(attn_fwd_kernel<64>, dim3(blocks), dim3(TPB), lds, (hipStream_t)stream, S, N, epb, q, e, m);
+    CM_HIP(hipGetLastError());
+    return CM_OK;
+}
+
+extern "C" int cm_attention_backward(int32_t S, int32_t N, int32_t E, const float *q, const float *e, const float *m,
+                                     const float *d_m, float *d_q, float *d_e, void *stream) {
+    if (!q || !e || !m || !d_m || !d_q || !d_e) return set_error(CM_ERR_ARG, "cm_attention_backward: null argument");
+    if (E != 64) return set_error(CM_ERR_ARG, "cm_attention_backward: embedding dim 64 only");
+    if (S <= 0) return CM_OK;
+    const size_t lds = attn_lds(N, E);
+    if (lds > 160 * 1024) return set_error(CM_ERR_ARG, "cm_attention_backward: n_agents too large");
+    static bool once = false;
+    if (!once) { CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_bwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
+    const int epb = agg_epb(N);
+    const int blocks = (int)std::min<long>((S + epb - 1) / epb, 256 * 8);
+    hipLaunchKernelGGL(attn_bwd_kernel<64>, dim3(blocks), dim3(TPB), lds, (hipStream_t)stream, S, N, epb, q, e, m, d_m, d_q, d_e);
     CM_HIP(hipGetLastError());
     return CM_OK;
 }

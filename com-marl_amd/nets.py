@@ -42,12 +42,12 @@ class MLPModule(nn.Module):
         self._layers = nn.ModuleList()
         prev = input_dim
         for size in hidden_sizes:
-            lin = nn.Linear(prev, size)
+            lin = HipLinear(prev, size)
             nn.init.xavier_uniform_(lin.weight)
             nn.init.zeros_(lin.bias)
             self._layers.append(nn.Sequential(OrderedDict(linear=lin, non_linearity=_Tanh())))
             prev = size
-        lin = nn.Linear(prev, output_dim)
+        lin = HipLinear(prev, output_dim)
         nn.init.xavier_uniform_(lin.weight)
         nn.init.zeros_(lin.bias)
         mods = OrderedDict(linear=lin)
@@ -61,6 +61,32 @@ class MLPModule(nn.Module):
         return self._output_layers[0](x)
 
 
+class _AttentionSoftmax(torch.autograd.Function):
+    """M = softmax_j(q_i . e_j) per sample, one HIP kernel each way instead of three batched N x N GEMMs."""
+
+    @staticmethod
+    def forward(ctx, q, e):
+        S, N, E = e.shape
+        q, e = q.contiguous(), e.contiguous()
+        m = torch.empty(S, N, N, dtype=e.dtype, device=e.device)
+        with torch.cuda.device(e.device):
+            L.check(L.lib().cm_attention_forward(S, N, E, L.ptr(q), L.ptr(e), L.ptr(m), L.current_stream()),
+                    "cm_attention_forward")
+        ctx.save_for_backward(q, e, m)
+        return m
+
+    @staticmethod
+    def backward(ctx, d_m):
+        q, e, m = ctx.saved_tensors
+        S, N, E = e.shape
+        d_m = d_m.contiguous()
+        d_q, d_e = torch.empty_like(q), torch.empty_like(e)
+        with torch.cuda.device(e.device):
+            L.check(L.lib().cm_attention_backward(S, N, E, L.ptr(q), L.ptr(e), L.ptr(m), L.ptr(d_m), L.ptr(d_q),
+                                                  L.ptr(d_e), L.current_stream()), "cm_attention_backward")
+        return d_q, d_e
+
+
 class AttentionModule(nn.Module):
     """'general' attention (attention_module.py:17-51): softmax_j((q W^T) . k_j)."""
 
@@ -69,11 +95,13 @@ class AttentionModule(nn.Module):
         if attention_type != "general":
             raise NotImplementedError("only attention_type='general' (the runners' default) is built")
         self.attention_type = attention_type
-        self.linear_in = nn.Linear(dimensions, dimensions, bias=False)
+        self.linear_in = HipLinear(dimensions, dimensions, bias=False)
 
     def forward(self, query):
-        scores = torch.matmul(self.linear_in(query), query.transpose(-2, -1))
-        return torch.softmax(scores, dim=-1)
+        q = self.linear_in(query)
+        if query.is_cuda and query.dim() == 3 and query.shape[-1] == 64:
+            return _AttentionSoftmax.apply(q, query)             # fused HIP op (cm_attention_forward/backward)
+        return torch.softmax(torch.matmul(q, query.transpose(-2, -1)), dim=-1)
 
 
 class GraphConvolutionModule(nn.Module):
@@ -89,6 +117,68 @@ class GraphConvolutionModule(nn.Module):
             self.weight.uniform_(-stdv, stdv)
             if self.bias is not None:
                 self.bias.uniform_(-stdv, stdv)
+
+
+def _wgrad(a2d, b2d, want_colsum):
+    """c[p][q] = sum_r a[r][p] b[r][q] (+ column sums of a) on the MFMA weight-gradient kernel."""
+    R, P = a2d.shape
+    Q = b2d.shape[1]
+    c = torch.zeros(P, Q, dtype=torch.float32, device=a2d.device)
+    cs = torch.zeros(P, dtype=torch.float32, device=a2d.device) if want_colsum else None
+    with torch.cuda.device(a2d.device):
+        L.check(L.lib().cm_linear_wgrad(R, P, Q, L.ptr(a2d), L.ptr(b2d), L.ptr(c), L.ptr(cs), L.current_stream()),
+                "cm_linear_wgrad")
+    return c, cs
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T + b with the weight / bias gradients on cm_linear_wgrad: over ~1e6 agent rows the library
+    GEMM for dW = dY^T X (tiny output, million-deep reduction) ran at ~10 TFLOP/s and dominated the update."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dx = dy.matmul(weight) if ctx.needs_input_grad[0] else None
+        dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        dw, db = _wgrad(dy2, x2, ctx.has_bias)
+        return dx, dw, db
+
+
+class _MatmulWFn(torch.autograd.Function):
+    """z = h W (GraphConvolutionModule, weight [in,out]) with dW on cm_linear_wgrad."""
+
+    @staticmethod
+    def forward(ctx, h, weight):
+        ctx.save_for_backward(h, weight)
+        return torch.matmul(h, weight)
+
+    @staticmethod
+    def backward(ctx, dz):
+        h, weight = ctx.saved_tensors
+        dh = dz.matmul(weight.t()) if ctx.needs_input_grad[0] else None
+        dw, _ = _wgrad(h.reshape(-1, h.shape[-1]).contiguous(), dz.reshape(-1, dz.shape[-1]).contiguous(), False)
+        return dh, dw
+
+
+def hip_linear(x, lin):
+    """nn.Linear forward; on the GPU with autograd on, the backward uses the custom weight-gradient kernel."""
+    if x.is_cuda and torch.is_grad_enabled() and lin.weight.requires_grad and max(lin.weight.shape) <= 128:
+        return _LinearFn.apply(x, lin.weight, lin.bias)
+    return torch.nn.functional.linear(x, lin.weight, lin.bias)
+
+
+class HipLinear(nn.Linear):
+    """nn.Linear (same parameters / state_dict) whose training backward runs on cm_linear_wgrad."""
+
+    def forward(self, x):
+        return hip_linear(x, self)
 
 
 class _MaskedAggregate(torch.autograd.Function):
@@ -200,7 +290,8 @@ class CommBaseNet(nn.Module):
         M = self.attention_layer(E)
         H = E
         for l, g in enumerate(self.gcn_layers):
-            H = masked_aggregate(M, adj, ch, l, torch.matmul(H, g.weight), g.bias)
+            hw = _MatmulWFn.apply(H, g.weight) if (H.is_cuda and torch.is_grad_enabled()) else torch.matmul(H, g.weight)
+            H = masked_aggregate(M, adj, ch, l, hw, g.bias)
         return E, H, M
 
     # -- weight pack for the fused C-ABI forward -----------------------------------------------

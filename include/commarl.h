@@ -190,6 +190,20 @@ int cm_masked_agg_backward(int32_t S, int32_t N, int32_t E, const float *attn, c
                            const float *chan, int64_t ch_stride, const float *hw, const float *out,
                            const float *d_out, float *d_attn, float *d_hw, float *d_bias, void *stream);
 
+/* Attention scores + softmax for the autograd path (attention_module.py:39-49):
+ *   m[s,i,:] = softmax_j(q[s,i,:] . e[s,j,:]),  q = linear_in(e) [S,N,E], e [S,N,E], m [S,N,N].
+ * backward: d_q, d_e [S,N,E] from d_m [S,N,N] (the d_e returned is only the key-side term). */
+int cm_attention_forward(int32_t S, int32_t N, int32_t E, const float *q, const float *e, float *m, void *stream);
+int cm_attention_backward(int32_t S, int32_t N, int32_t E, const float *q, const float *e, const float *m,
+                          const float *d_m, float *d_q, float *d_e, void *stream);
+
+/* Weight gradient of a per-agent dense layer over R rows: c[p][q] += sum_r a[r][p] * b[r][q] (c [P,Q] must be
+ * zeroed by the caller; accumulated with float atomics), colsum_a[p] += sum_r a[r][p] (or NULL).
+ * nn.Linear backward: a = dY [R,out], b = X [R,in] -> c = dW [out,in], colsum_a = db.
+ * GraphConvolutionModule (H.W, graph_conv_module.py:63): a = H [R,in], b = dZ [R,out] -> c = dW [in,out]. */
+int cm_linear_wgrad(int64_t R, int32_t P, int32_t Q, const float *a, const float *b, float *c, float *colsum_a,
+                    void *stream);
+
 /* tensor_utils.discount_cumsum (garage/misc/tensor_utils.py:7-23) per path over a padded
  * [P,T] batch: f64 recurrence, f32 result, zero past lens[p]. */
 int cm_discount_returns(int32_t P, int32_t T, const double *rewards, const int32_t *lens, double gamma,

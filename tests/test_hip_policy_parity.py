@@ -176,3 +176,53 @@ def test_returns_gae_kernels(torch_cuda):
     # per-path normalisation divides by sqrt(var + 1e-8): very short paths amplify f32-vs-f64 rounding,
     # so this stress case uses a looser bar than the golden-vector check above (1e-5)
     np.testing.assert_allclose(adv.cpu().numpy(), want, rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("S,N", [(50, 4), (7, 24), (3, 54), (2, 72), (11, 3)])
+def test_attention_softmax_op(S, N, torch_cuda):
+    """fused scores+softmax (cm_attention_forward/backward) vs the plain PyTorch f32 ops it replaces"""
+    torch = torch_cuda
+    from com_marl_amd.nets import _AttentionSoftmax
+    g = torch.Generator().manual_seed(S + N)
+    q = (torch.randn(S, N, 64, generator=g) * 0.3).cuda().requires_grad_()
+    e = (torch.randn(S, N, 64, generator=g) * 0.3).cuda().requires_grad_()
+    w = torch.randn(S, N, N, generator=g).cuda()
+    m = _AttentionSoftmax.apply(q, e)
+    ref = torch.softmax(torch.matmul(q, e.transpose(-2, -1)), dim=-1)
+    np.testing.assert_allclose(m.detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=1e-5, atol=1e-6)
+    g1 = torch.autograd.grad((m * w).sum(), (q, e))
+    g2 = torch.autograd.grad((ref * w).sum(), (q, e))
+    for a, b in zip(g1, g2):
+        bn = b.cpu().numpy()
+        np.testing.assert_allclose(a.cpu().numpy(), bn, rtol=2e-4, atol=1e-5 * max(1.0, float(np.abs(bn).max())))
+
+
+@pytest.mark.parametrize("R,IN,OUT", [(1000, 21, 128), (70001, 128, 64), (4097, 64, 64), (333, 64, 128), (5000, 32, 5),
+                                      (129, 64, 1), (64, 77, 128), (100000, 128, 128)])
+def test_linear_weight_gradient_kernel(R, IN, OUT, torch_cuda):
+    """cm_linear_wgrad (f32 MFMA, atomics merge) vs torch autograd for nn.Linear and the GCN H.W product"""
+    torch = torch_cuda
+    from com_marl_amd.nets import HipLinear, _MatmulWFn
+    g = torch.Generator().manual_seed(R + IN + OUT)
+    x = torch.randn(R, IN, generator=g).cuda()
+    dy = torch.randn(R, OUT, generator=g).cuda()
+    lin = HipLinear(IN, OUT).cuda()
+    xr = x.clone().requires_grad_()
+    y = lin(xr)
+    y.backward(dy)
+    ref = torch.nn.Linear(IN, OUT).cuda()
+    ref.load_state_dict(lin.state_dict())
+    xr2 = x.clone().requires_grad_()
+    ref(xr2).backward(dy)
+    scale = float(ref.weight.grad.abs().max())
+    np.testing.assert_allclose(lin.weight.grad.cpu().numpy(), ref.weight.grad.cpu().numpy(), rtol=2e-4, atol=2e-5 * scale)
+    np.testing.assert_allclose(lin.bias.grad.cpu().numpy(), ref.bias.grad.cpu().numpy(), rtol=2e-4,
+                               atol=2e-5 * float(ref.bias.grad.abs().max()))
+    np.testing.assert_allclose(xr.grad.cpu().numpy(), xr2.grad.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    if IN == OUT == 64:
+        w = torch.randn(64, 64, generator=g).cuda().requires_grad_()
+        h = x.reshape(-1, 1, 64).clone().requires_grad_()
+        _MatmulWFn.apply(h, w).backward(dy.reshape(-1, 1, 64))
+        w2 = w.detach().clone().requires_grad_()
+        torch.matmul(x, w2).backward(dy)
+        np.testing.assert_allclose(w.grad.cpu().numpy(), w2.grad.cpu().numpy(), rtol=2e-4, atol=2e-5 * float(w2.grad.abs().max()))
