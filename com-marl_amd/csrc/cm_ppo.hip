@@ -302,8 +302,16 @@ __global__ __launch_bounds__(TPB) void wgrad_kernel(long R, int P, int Q, const 
     const int SP = PT * 16 + 16, SQ = QT * 16 + 16;          // row strides == 16 (mod 32): conflict-free operand reads
     float *As = lds, *Bs = As + (size_t)WG_ROWS * SP;
     v4f acc[MAXT];
+    int aoff[MAXT], boff[MAXT];       // per-tile operand offsets, hoisted out of the k loop (no division per MFMA)
 #pragma unroll
-    for (int t = 0; t < MAXT; ++t) acc[t] = (v4f){ 0.f, 0.f, 0.f, 0.f };
+    for (int t = 0; t < MAXT; ++t) {
+        acc[t] = (v4f){ 0.f, 0.f, 0.f, 0.f };
+        const int tile = wave + 4 * t;
+        const int tl = tile < NT ? tile : 0;              // idle slots recompute tile 0 and are never stored
+        const int pt = tl / QT, qt = tl - pt * QT;
+        aoff[t] = g * SP + c + pt * 16;
+        boff[t] = g * SQ + c + qt * 16;
+    }
     float csum = 0.0f;
     // zero the padding columns once (they feed MFMAs whose results are never stored)
     for (int k = tid; k < WG_ROWS * SP; k += TPB) As[k] = 0.0f;
@@ -317,17 +325,14 @@ __global__ __launch_bounds__(TPB) void wgrad_kernel(long R, int P, int Q, const 
         stage_rows(Bs, SQ, B, Q, r0, rows, tid);
         __syncthreads();
         if (colsum_a && tid < P) { float sacc = 0.0f; for (int r = 0; r < WG_ROWS; ++r) sacc += As[(size_t)r * SP + tid]; csum += sacc; }
-#pragma unroll 4
+#pragma unroll 2
         for (int kk = 0; kk < WG_ROWS / 4; ++kk) {
-            const float *ar = As + (size_t)(4 * kk + g) * SP + c, *br = Bs + (size_t)(4 * kk + g) * SQ + c;
+            const float *ar = As + (size_t)(4 * kk) * SP, *br = Bs + (size_t)(4 * kk) * SQ;
+            float av[MAXT], bw[MAXT];
 #pragma unroll
-            for (int t = 0; t < MAXT; ++t) {
-                const int tile = wave + 4 * t;
-                if (tile < NT) {
-                    const int pt = tile / QT, qt = tile - pt * QT;
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[pt * 16], br[qt * 16], acc[t], 0, 0, 0);
-                }
-            }
+            for (int t = 0; t < MAXT; ++t) { av[t] = ar[aoff[t]]; bw[t] = br[boff[t]]; }
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bw[t], acc[t], 0, 0, 0);
         }
         __syncthreads();
     }
@@ -446,12 +451,15 @@ extern "C" int cm_linear_wgrad(int64_t R, int32_t P, int32_t Q, const float *a, 
     if (!once) {
         CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         once = true;
     }
-    if (per_wave <= 2) hipLaunchKernelGGL(wgrad_kernel<2>, dim3(blocks), dim3(TPB), lds, st, (long)R, P, Q, a, b, c, colsum_a);
-    else if (per_wave <= 8) hipLaunchKernelGGL(wgrad_kernel<8>, dim3(blocks), dim3(TPB), lds, st, (long)R, P, Q, a, b, c, colsum_a);
-    else hipLaunchKernelGGL(wgrad_kernel<16>, dim3(blocks), dim3(TPB), lds, st, (long)R, P, Q, a, b, c, colsum_a);
+#define CM_WG(M) hipLaunchKernelGGL(wgrad_kernel<M>, dim3(blocks), dim3(TPB), lds, st, (long)R, P, Q, a, b, c, colsum_a)
+    if (per_wave <= 1) CM_WG(1); else if (per_wave <= 2) CM_WG(2); else if (per_wave <= 4) CM_WG(4);
+    else if (per_wave <= 8) CM_WG(8); else CM_WG(16);
+#undef CM_WG
     CM_HIP(hipGetLastError());
     return CM_OK;
 }
