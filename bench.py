@@ -135,15 +135,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs the MI355X; there is no CPU path")
+    # one rank per GPU; COMMARL_DIST_BACKEND=gloo lets several ranks share one GPU to rehearse the N>1 path
+    backend = os.environ.get("COMMARL_DIST_BACKEND", "nccl")
+    dev = torch.device("cuda", local % torch.cuda.device_count())
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs the MI355X; there is no CPU path")
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from com_marl_amd import envs as E, nets
     from com_marl_amd.rollout import RolloutEngine
@@ -222,7 +226,7 @@ def main():
     flops = policy_flops(c, env.d) * B
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and B == CONFIGS[args.config]["envs"]:      # PMC figures are per launch of the default batch
         try:
             traffic = json.load(open(tpath)).get(args.config)
         except Exception:

@@ -233,6 +233,8 @@ class CentralizedMAPPO:
             old_ll = self._old_log_likelihood(obs, actions, dist_adjs, channels)
 
         step_size = int(np.ceil(P / self._optimization_n_minibatches))
+        if distributed and P < 2 * self._optimization_n_minibatches:
+            raise RuntimeError("distributed update needs >= 2 paths per minibatch on every rank (equal optimiser-step counts)")
         shuffled_ids = np.random.permutation(P)                                      # :209
         grad_norm = []
         sl = lambda x, ids: None if x is None else x[ids]                            # noqa: E731
