@@ -41,13 +41,14 @@ class EnvState(C.Structure):
 
 class PolicyWeights(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("d", "n_agents", "n_hops", "enc_hidden", "emb", "h1", "h2", "h3", "n_act",
-                                         "_pad")] + [
+                                         "no_residual")] + [
         (n, C.c_void_p) for n in ("enc_w1t", "enc_b1", "enc_w2t", "enc_b2", "attn_wt", "gcn_w", "gcn_b", "hd_w1t",
                                   "hd_b1", "hd_w2t", "hd_b2", "hd_w3t", "hd_b3", "hd_w4t", "hd_b4")]
 
 
 class CriticWeights(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("d", "n_agents", "n_hops", "enc_hidden", "emb", "dec_hidden")] + [
+    _fields_ = [(n, C.c_int32) for n in ("d", "n_agents", "n_hops", "enc_hidden", "emb", "dec_hidden",
+                                         "no_residual", "_pad")] + [
         (n, C.c_void_p) for n in ("enc_w1t", "enc_b1", "enc_w2t", "enc_b2", "attn_wt", "gcn_w", "gcn_b", "dec_w1t",
                                   "dec_b1", "dec_w2t", "dec_b2")]
 

@@ -38,7 +38,7 @@ struct FwdArgs {
     const float *obs, *avail, *adj, *chan;
     uint32_t key0, key1, policy_step;
     const uint32_t *step_base;
-    int env_id_offset, greedy;
+    int env_id_offset, greedy, no_residual;
     int32_t *actions;
     float *probs, *attn, *values;
 };
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(TPB) void fwd_kernel(FwdArgs a, TrunkW tw, PolHead 
         __syncthreads();
     }
     // ---- residual (comm_categorical_mlp_policy.py:74-77) ----
-    for (int k = tid; k < rows * EMB; k += TPB) { const int r = k >> 6, o = k & 63; H[(size_t)r * SE + o] = E[(size_t)r * SE + o] + (L > 0 ? H[(size_t)r * SE + o] : 0.0f); }
+    for (int k = tid; k < rows * EMB; k += TPB) { const int r = k >> 6, o = k & 63; H[(size_t)r * SE + o] = (L > 0 ? H[(size_t)r * SE + o] : 0.0f) + ((a.no_residual && L > 0) ? 0.0f : E[(size_t)r * SE + o]); }
     __syncthreads();
 
     if (HEAD == 0) {
@@ -305,7 +305,7 @@ extern "C" int cm_policy_forward(const cm_policy_weights *w, int32_t n_samples, 
     a.S = n_samples; a.N = w->n_agents; a.d = w->d; a.L = w->n_hops;
     a.obs = obs; a.avail = avail; a.adj = dist_adj; a.chan = channels;
     a.key0 = (uint32_t)seed; a.key1 = (uint32_t)(seed >> 32); a.policy_step = policy_step; a.step_base = policy_step_base;
-    a.env_id_offset = env_id_offset; a.greedy = greedy;
+    a.env_id_offset = env_id_offset; a.greedy = greedy; a.no_residual = w->no_residual;
     a.actions = actions; a.probs = probs; a.attn = attn;
     TrunkW tw{ w->enc_w1t, w->enc_b1, w->enc_w2t, w->enc_b2, w->attn_wt, w->gcn_w, w->gcn_b };
     PolHead ph{ w->hd_w1t, w->hd_b1, w->hd_w2t, w->hd_b2, w->hd_w3t, w->hd_b3, w->hd_w4t, w->hd_b4, w->n_act };
@@ -325,7 +325,7 @@ extern "C" int cm_critic_forward(const cm_critic_weights *w, int32_t n_samples, 
     }
     FwdArgs a{};
     a.S = n_samples; a.N = w->n_agents; a.d = w->d; a.L = w->n_hops;
-    a.obs = obs; a.adj = dist_adj; a.chan = channels; a.values = values;
+    a.obs = obs; a.adj = dist_adj; a.chan = channels; a.values = values; a.no_residual = w->no_residual;
     TrunkW tw{ w->enc_w1t, w->enc_b1, w->enc_w2t, w->enc_b2, w->attn_wt, w->gcn_w, w->gcn_b };
     CritHead chd{ w->dec_w1t, w->dec_b1, w->dec_w2t, w->dec_b2 };
     return launch_fwd<1>(a, tw, PolHead{}, chd, stream);

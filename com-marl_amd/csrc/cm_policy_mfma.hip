@@ -48,7 +48,7 @@ struct FwdArgs {
     const float *obs, *avail, *adj, *chan;
     uint32_t key0, key1, policy_step;
     const uint32_t *step_base;
-    int env_id_offset, greedy;
+    int env_id_offset, greedy, no_residual;
     int32_t *actions;
     float *probs, *attn, *values;
     int stop;          // diagnostic: return after phase `stop` (0 = run everything); COMMARL_FWD_STOP
@@ -217,20 +217,38 @@ __global__ __launch_bounds__(TPB) void fwd_mfma_kernel(FwdArgs a, TrunkW tw, Pol
         const float *Hin = (l == 0) ? E : H;
         l_sq.template run<false>(Hin, SE, T, SE, RT, wave, lane);                              // H.Wg_l
         if (l + 1 < L) l_sq.load(tw.gcn_w + (size_t)(l + 1) * EMB * EMB, nullptr, EMB, wave, lane);
-        for (int k = tid; k < envs * NN; k += TPB) {    // A = M * Range * Chan_l (coalesced mask reads)
-            const int e = k / NN, ij = k - e * NN, r = k / N, j = k - r * N;
-            float v = M[(size_t)r * NP + j];
-            if (a.adj) v *= a.adj[(size_t)(s0 + e) * NN + ij];
-            if (a.chan) v *= a.chan[((size_t)(s0 + e) * L + l) * NN + ij];
-            Amat[(size_t)r * NP + j] = v;
-        }
-        __syncthreads();
-        for (int r = tid; r < rows; r += TPB) {
-            float *ar = Amat + (size_t)r * NP;
-            float sum = 0.0f;
-            for (int j = 0; j < N; ++j) sum += ar[j];
-            const float den = sum + 1e-12f;
-            for (int j = 0; j < N; ++j) ar[j] = ar[j] / den;
+        if (N <= 16) {
+            // small teams: one thread builds its whole masked + renormalised row (no intermediate barrier)
+            for (int r = tid; r < rows; r += TPB) {
+                const int e = r / N, i = r - e * N;
+                const float *mr = M + (size_t)r * NP;
+                float *ar = Amat + (size_t)r * NP;
+                float sum = 0.0f;
+                for (int j = 0; j < N; ++j) {
+                    float v = mr[j];
+                    if (a.adj) v *= a.adj[(size_t)(s0 + e) * NN + i * N + j];
+                    if (a.chan) v *= a.chan[((size_t)(s0 + e) * L + l) * NN + i * N + j];
+                    ar[j] = v; sum += v;
+                }
+                const float den = sum + 1e-12f;
+                for (int j = 0; j < N; ++j) ar[j] = ar[j] / den;
+            }
+        } else {
+            for (int k = tid; k < envs * NN; k += TPB) {    // A = M * Range * Chan_l (coalesced mask reads)
+                const int e = k / NN, ij = k - e * NN, r = k / N, j = k - r * N;
+                float v = M[(size_t)r * NP + j];
+                if (a.adj) v *= a.adj[(size_t)(s0 + e) * NN + ij];
+                if (a.chan) v *= a.chan[((size_t)(s0 + e) * L + l) * NN + ij];
+                Amat[(size_t)r * NP + j] = v;
+            }
+            __syncthreads();
+            for (int r = tid; r < rows; r += TPB) {
+                float *ar = Amat + (size_t)r * NP;
+                float sum = 0.0f;
+                for (int j = 0; j < N; ++j) sum += ar[j];
+                const float den = sum + 1e-12f;
+                for (int j = 0; j < N; ++j) ar[j] = ar[j] / den;
+            }
         }
         __syncthreads();
         {
@@ -250,18 +268,20 @@ __global__ __launch_bounds__(TPB) void fwd_mfma_kernel(FwdArgs a, TrunkW tw, Pol
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (r0 + i < rows && (r0 + i) / N == e) H[(size_t)(r0 + i) * SE + o] = fast_tanh(acc[i] + bv);
+                    if (r0 + i < rows && (r0 + i) / N == e) {
+                        const float hv = fast_tanh(acc[i] + bv);      // last hop: write E + H_L (residual, policy :74-77)
+                        H[(size_t)(r0 + i) * SE + o] = (l == L - 1 && !a.no_residual) ? E[(size_t)(r0 + i) * SE + o] + hv : hv;
+                    }
             }
         }
         __syncthreads();
     }
     if (a.stop == 6) return;
     // ---- residual ----
-    for (int k = tid; k < rows * EMB; k += TPB) {
-        const int r = k >> 6, o = k & 63;
-        H[(size_t)r * SE + o] = E[(size_t)r * SE + o] + (L > 0 ? H[(size_t)r * SE + o] : 0.0f);
+    if (L == 0) {                                       // no hops: x = E (the hop epilogue adds the residual otherwise)
+        for (int k = tid; k < rows * EMB; k += TPB) { const int r = k >> 6, o = k & 63; H[(size_t)r * SE + o] = E[(size_t)r * SE + o]; }
+        __syncthreads();
     }
-    __syncthreads();
 
     if (HEAD == 0) {
         Layer<EMB, H1> l_h1;
@@ -392,7 +412,7 @@ int policy_forward_mfma(const cm_policy_weights *w, int32_t S, const float *obs,
     a.S = S; a.N = w->n_agents; a.d = w->d; a.L = w->n_hops;
     a.obs = obs; a.avail = avail; a.adj = adj; a.chan = chan;
     a.key0 = (uint32_t)seed; a.key1 = (uint32_t)(seed >> 32); a.policy_step = policy_step; a.step_base = step_base;
-    a.env_id_offset = env_id_offset; a.greedy = greedy;
+    a.env_id_offset = env_id_offset; a.greedy = greedy; a.no_residual = w->no_residual;
     a.actions = actions; a.probs = probs; a.attn = attn;
     { const char *e = getenv("COMMARL_FWD_STOP"); a.stop = e ? atoi(e) : 0; }
     mf::TrunkW tw{ w->enc_w1t, w->enc_b1, w->enc_w2t, w->enc_b2, w->attn_wt, w->gcn_w, w->gcn_b };
@@ -404,7 +424,7 @@ int critic_forward_mfma(const cm_critic_weights *w, int32_t S, const float *obs,
                         float *values, void *stream) {
     mf::FwdArgs a{};
     a.S = S; a.N = w->n_agents; a.d = w->d; a.L = w->n_hops;
-    a.obs = obs; a.adj = adj; a.chan = chan; a.values = values;
+    a.obs = obs; a.adj = adj; a.chan = chan; a.values = values; a.no_residual = w->no_residual;
     mf::TrunkW tw{ w->enc_w1t, w->enc_b1, w->enc_w2t, w->enc_b2, w->attn_wt, w->gcn_w, w->gcn_b };
     mf::CritHead chd{ w->dec_w1t, w->dec_b1, w->dec_w2t, w->dec_b2 };
     return mf::dispatch<1>(a, tw, mf::PolHead{}, chd, stream);

@@ -419,6 +419,7 @@ class CommCategoricalMLPPolicy(CommBaseNet):
         w.enc_hidden, w.emb = self._enc_hidden[0], self._embedding_dim
         w.h1, w.h2, w.h3 = self._head_sizes
         w.n_act = self._action_dim
+        w.no_residual = 0 if self.residual else 1
         for k, v in p.items():
             setattr(w, k, v)
         return w
@@ -533,6 +534,7 @@ class CommBaseCritic(CommBaseNet):
         w = L.CriticWeights()
         w.d, w.n_agents, w.n_hops = self._dec_obs_dim, N, len(self.gcn_layers)
         w.enc_hidden, w.emb, w.dec_hidden = self._enc_hidden[0], self._embedding_dim, self._dec_hidden[0]
+        w.no_residual = 0 if self.residual else 1
         for k, v in p.items():
             setattr(w, k, v)
         with torch.cuda.device(dev):

@@ -141,7 +141,7 @@ int cm_env_set_state(cm_env_t h, const cm_env_state *host);
  * output index) - the veneer keeps a transposed device copy; GCN weights are already [in,out]. */
 typedef struct cm_policy_weights {
     int32_t d, n_agents, n_hops, enc_hidden, emb, h1, h2, h3, n_act;
-    int32_t _pad;
+    int32_t no_residual;             /* 0 (default): x = E + H_L (comm_categorical_mlp_policy.py:74-77); 1: x = H_L */
     const float *enc_w1t, *enc_b1;   /* encoder._layers.0.linear.{weight^T,bias}          [d,128],[128] */
     const float *enc_w2t, *enc_b2;   /* encoder._output_layers.0.linear.*                 [128,64],[64] */
     const float *attn_wt;            /* attention_layer.linear_in.weight^T                [64,64] */
@@ -154,6 +154,7 @@ typedef struct cm_policy_weights {
 
 typedef struct cm_critic_weights {
     int32_t d, n_agents, n_hops, enc_hidden, emb, dec_hidden;
+    int32_t no_residual, _pad;
     const float *enc_w1t, *enc_b1, *enc_w2t, *enc_b2, *attn_wt, *gcn_w, *gcn_b;
     const float *dec_w1t, *dec_b1;   /* baseline_aggregator._mean_module._layers.0.linear.*        [64,64] */
     const float *dec_w2t, *dec_b2;   /* baseline_aggregator._mean_module._output_layers.0.linear.* [64,1] */

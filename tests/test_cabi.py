@@ -36,7 +36,7 @@ def test_struct_layouts_match_header_sizes():
     assert C.sizeof(_lib.StepOut) == 10 * 8
     assert C.sizeof(_lib.EnvState) == 9 * 8
     assert C.sizeof(_lib.PolicyWeights) == 10 * 4 + 15 * 8
-    assert C.sizeof(_lib.CriticWeights) == 6 * 4 + 11 * 8
+    assert C.sizeof(_lib.CriticWeights) == 8 * 4 + 11 * 8
 
 
 def test_argument_errors_without_gpu():
