@@ -122,6 +122,7 @@ def main():
     ap.add_argument("--config", default="pp_map10", choices=sorted(CONFIGS))
     ap.add_argument("--envs", type=int, default=None, help="envs per GPU (default: the config's)")
     ap.add_argument("--chunk", type=int, default=50, help="steps per captured hipGraph")
+    ap.add_argument("--streams", type=int, default=2, help="independent env shards per GPU, one HIP stream each")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-loop", action="store_true")
@@ -156,12 +157,18 @@ def main():
     B = args.envs or c["envs"]
     c["envs"] = B
     env = E.GridEnvBatch(c["scenario"], env_params(c), B, device=dev, seed=args.seed, env_id_offset=rank * B)
+    ns = args.streams if (args.streams > 1 and B % args.streams == 0) else 1
+    if ns > 1:      # the same B envs (same global ids, same Philox streams) as `ns` shards, each on its own stream
+        shards = [E.GridEnvBatch(c["scenario"], env_params(c), B // ns, device=dev, seed=args.seed,
+                                 env_id_offset=rank * B + k * (B // ns)) for k in range(ns)]
+    else:
+        shards = [env]
     spec = E.EnvSpec(E._Box(np.zeros(env.d * env.N), np.ones(env.d * env.N)), E._Discrete(5))
     torch.manual_seed(args.seed)                       # replicas: identical weights on every rank
     policy = nets.CommCategoricalMLPPolicy(spec, n_agents=env.N, device=dev)
     policy.set_rng(args.seed, env_id_offset=rank * B)
     G = max(1, min(args.chunk, args.steps))
-    eng = RolloutEngine(env, policy, horizon=G)
+    eng = RolloutEngine(shards, policy, horizon=G)
     eng.reset()
 
     def barrier():
@@ -173,9 +180,12 @@ def main():
         full, rest = divmod(n, G)
         for _ in range(full):
             eng.run_chunk(use_graph=not args.no_graph)
+        if rest:
+            eng.fork()
         for t in range(rest):                          # remainder steps outside the captured chunk
             eng.step(t)
             if t == rest - 1:
+                eng.join()
                 eng.obs[0].copy_(eng.obs[rest])
                 if eng.dist_adj is not None:
                     eng.dist_adj[0].copy_(eng.dist_adj[rest])
@@ -183,13 +193,13 @@ def main():
                     eng.channels[0].copy_(eng.channels[rest])
 
     run(args.warmup)
-    env.check_status()
+    eng.env.check_status()
     barrier()
     t0 = time.perf_counter()
     run(args.steps)
     barrier()
     dt = time.perf_counter() - t0
-    env.check_status()
+    eng.env.check_status()
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -203,7 +213,7 @@ def main():
         fn()
         torch.cuda.synchronize(dev)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):   # NCCL's watchdog thread may touch HIP during capture
             for _ in range(inner):
                 fn()
         g.replay()
@@ -216,11 +226,12 @@ def main():
         ev1.synchronize()
         return ev0.elapsed_time(ev1) / (reps * inner) * 1e-3                 # seconds per launch
 
+    env.reset_all()                                     # full-batch handle: per-launch kernel times at B envs
     t_pol = time_kernel(lambda: policy.act_device(
         eng.obs[0].view(B, -1), None, None if eng.dist_adj is None else eng.dist_adj[0],
         None if eng.channels is None else eng.channels[0], out_actions=eng.actions[0], out_probs=eng.probs[0],
         out_attn=eng.attn[0], policy_step=0, step_base=eng.step_base))
-    t_env = time_kernel(lambda: env.step_device(eng.actions[0], out=eng._out(0)))
+    t_env = time_kernel(lambda: env.step_device(eng.actions[0], out=eng._out(0, 0, B)))
     env.check_status()
     b_env, b_pol = algorithmic_bytes(c, env.d, env.adj_const, env.ch_const)
     flops = policy_flops(c, env.d) * B
@@ -252,7 +263,7 @@ def main():
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32 (policy GEMMs) + int32/u8 (grid state)", "data": "synthetic",
         "config": {"workload": c["label"], "envs_per_gpu": B, "total_envs": B * world, "n_agents": c["n_agents"],
-                   "obs_dim": env.d, "graph_chunk": 0 if args.no_graph else G,
+                   "obs_dim": env.d, "graph_chunk": 0 if args.no_graph else G, "streams": ns,
                    "parallelism": f"env-sharded x{world} (no data-path collective in the rollout)"},
         "roofline": roofline,
     }

@@ -102,11 +102,18 @@ __device__ __forceinline__ uint8_t &PCNT(const Lds l, int i) { return smem[l.pcn
 __device__ __forceinline__ uint8_t &PMV(const Lds l, int i) { return smem[l.pmv + chk(l, i, nM, 9)]; }
 __device__ __forceinline__ uint32_t &VIS(const Lds l, int i) { return reinterpret_cast<uint32_t *>(smem + l.vis)[chk(l, i, nS, 10)]; }
 
-__device__ __forceinline__ int cell(const Lds l, int r, int c, int S) { return in_grid(r, c, S) ? (int)Gc(l, r * S + c) : -1; }
+// Branch-free probes: the address is clamped into the tile and the result masked by the bounds test, so the
+// four neighbour reads of count_adj are independent LDS loads (one round trip) instead of four dependent
+// short-circuit branches.
+__device__ __forceinline__ int cell(const Lds l, int r, int c, int S) {
+    const int rr = min(max(r, 0), S - 1), cc = min(max(c, 0), S - 1);
+    const int v = (int)Gc(l, rr * S + cc);
+    return in_grid(r, c, S) ? v : -1;
+}
 // _neighbour_agents / _neighbour_preys count (predator_prey.py:309-351): D,U,R,L, each bounds-checked
 __device__ __forceinline__ int count_adj(const Lds l, int r, int c, int S, int kind) {
-    return (cell(l, r + 1, c, S) == kind) + (cell(l, r - 1, c, S) == kind) + (cell(l, r, c + 1, S) == kind) +
-           (cell(l, r, c - 1, S) == kind);
+    const int a = cell(l, r + 1, c, S), b = cell(l, r - 1, c, S), d = cell(l, r, c + 1, S), e = cell(l, r, c - 1, S);
+    return (a == kind) + (b == kind) + (d == kind) + (e == kind);
 }
 
 struct Rng {
@@ -378,11 +385,13 @@ __global__ __launch_bounds__(WAVE) void env_kernel(EnvDev p, const int32_t *__re
     if (env_bad && sl == 0 && valid) raise(p, CM_ERR_ACTION);
     const bool commit = valid && !env_bad;
     __syncthreads();
+    if (p.stop == 1) return;
     for (int i = sl; i < N; i += LPE) Gc(l, AR(l, i) * S + AC(l, i)) = C_AGENT;
     if (SCEN == CM_PP)
         for (int j = sl; j < M; j += LPE) if (ALV(l, j)) Gc(l, PR(l, j) * S + PC(l, j)) = C_PREY;
     __syncthreads();
 
+    if (p.stop == 2) return;
     int step_count = p.step_count[b] + 1;
     int succ = p.success[b];
     int done = 0;
@@ -405,6 +414,7 @@ __global__ __launch_bounds__(WAVE) void env_kernel(EnvDev p, const int32_t *__re
             if (mv && sl == 0) { Gc(l, r * S + c) = C_EMPTY; Gc(l, nr * S + nc) = C_AGENT; AR(l, i) = (int16_t)nr; AC(l, i) = (int16_t)nc; }
             __syncthreads();
         }
+        if (p.stop == 3) return;
         // ---- per-prey work that only depends on the (now static) agent layer: one lane per prey ----
         for (int j = sl; j < M; j += LPE) {
             int cnt = 0, mv = 4;
@@ -439,6 +449,7 @@ __global__ __launch_bounds__(WAVE) void env_kernel(EnvDev p, const int32_t *__re
             wsum += g.count(w);
         }
         __syncthreads();
+        if (p.stop == 4) return;
         // ---- captures + prey moves in index order (:416-432 / :460-478, :276-301): group-uniform loop ----
         int capture = 0, penalty = 0;
         bool tape_short = false;
@@ -475,9 +486,12 @@ __global__ __launch_bounds__(WAVE) void env_kernel(EnvDev p, const int32_t *__re
             }
             __syncthreads();
         }
+        if (p.stop == 5) return;
         if (tape_short && sl == 0 && commit) raise(p, CM_ERR_TAPE_PREY);
         // reward in f64 exactly as the Python expression evaluates (:434 / :480); no FMA contraction (build flag)
-        reward = (p.step_cost + p.cap_rew * (double)capture) + (p.move_cost * (double)moving) / (double)N;
+        // (step + cap*c) + (mc*m)/N [+ pen*p]: the two count-indexed terms come from host tables built with the
+        // same f64 operations (no f64 division on the device)
+        reward = p.rew_lut[capture] + p.rew_lut[(M + 1) + moving];
         if (p.load == 2) reward = reward + p.penalty * (double)penalty;
         det0 = capture; det1 = moving; det2 = penalty; det4 = wsum;
         bool any_alive = false;
@@ -512,12 +526,13 @@ __global__ __launch_bounds__(WAVE) void env_kernel(EnvDev p, const int32_t *__re
         if (total == p.n_empty) { fin = p.final_reward; done = 1; }     // :381-385
         if (step_count >= p.max_steps) { succ = done ? 1 : 0; done = 1; }   // :388-393
         if (sl == 0 && commit) p.total_capture[b] = total;
-        const double n = (double)N;                                      // get_reward (:299-317), left-to-right
-        reward = p.step_cost + p.cap_rew * ((double)cap / n);
-        reward = reward + p.move_cost * ((double)mov / n);
-        reward = reward + p.penalty * ((double)pen / n);
-        reward = reward + p.lazy * ((double)lazy / n);
-        reward = reward + p.revisit * ((double)rev / n);
+        // get_reward (:299-317), left-to-right; term_k[count] = coef_k * (count / N) tabulated on the host in f64
+        const double *T = p.rew_lut;
+        reward = p.step_cost + T[cap];
+        reward = reward + T[(N + 1) + mov];
+        reward = reward + T[2 * (N + 1) + pen];
+        reward = reward + T[3 * (N + 1) + lazy];
+        reward = reward + T[4 * (N + 1) + rev];
         reward = reward + fin;
         det0 = cap; det1 = mov; det2 = pen; det3 = lazy; det4 = rev; det5 = fin != 0.0;
     }
@@ -535,10 +550,11 @@ __global__ __launch_bounds__(WAVE) void env_kernel(EnvDev p, const int32_t *__re
         p.rng_step[b] = rng.step + 1;
     }
     __syncthreads();
+    if (p.stop == 6) return;
     // auto-reset (:36-43): groups whose env finished re-spawn and emit the reset observation
     do_reset<SCEN, LPE>(p, l, rng, tape, b, g, done != 0);
     if (done) step_count = 0;
-    if (!commit) return;
+    if (!commit || p.stop == 7) return;
     if (sl == 0) {
         if (done && SCEN == CM_CO) p.total_capture[b] = 0;
         p.step_count[b] = step_count;
@@ -634,6 +650,15 @@ extern "C" int cm_env_create(const cm_env_cfg *cfg, cm_env_t *out) {
         for (uint8_t v : walls) n += (v == C_EMPTY);
         d.n_empty = n - c.n_agents;                                     // coverage.py:228-230
     }
+    std::vector<double> rew_lut;
+    if (c.scenario == CM_PP) {           // [0..M]: step + cap*c ; [M+1 .. M+1+N]: (mc*m)/N   (predator_prey.py:434,480)
+        for (int k = 0; k <= M; ++k) rew_lut.push_back(c.step_cost + c.capture_reward * (double)k);
+        for (int k = 0; k <= c.n_agents; ++k) rew_lut.push_back((c.move_cost * (double)k) / (double)c.n_agents);
+    } else {                             // 5 x [0..N]: coef * (count / N)               (coverage.py:299-306)
+        const double coef[5] = { c.capture_reward, c.move_cost, c.penalty, c.lazy_penalty, c.revisit_penalty };
+        for (int t = 0; t < 5; ++t)
+            for (int k = 0; k <= c.n_agents; ++k) rew_lut.push_back(coef[t] * ((double)k / (double)c.n_agents));
+    }
     std::vector<float> lut_row(S), lut_col(S), lut_step(c.max_steps + 1);
     for (int i = 0; i < S; ++i) {
         if (c.scenario == CM_PP) { lut_row[i] = (float)((double)i / (double)S); lut_col[i] = (float)((double)i / (double)(S - 1)); }
@@ -648,7 +673,8 @@ extern "C" int cm_env_create(const cm_env_cfg *cfg, cm_env_t *out) {
     const size_t o_ap = take(B * N * sizeof(int2)), o_pp = take(B * (M ? M : 1) * sizeof(int2)), o_al = take(B * (M ? M : 1)),
                  o_vis = take(B * S * 4), o_sc = take(B * 4), o_tc = take(B * 4), o_su = take(B * 4),
                  o_ge = take(c.channel == CM_CH_GE ? B * N * N : 1), o_rs = take(B * 4), o_st = take(4),
-                 o_bg = take((size_t)S * S), o_lr = take(S * 4), o_lc = take(S * 4), o_ls = take((c.max_steps + 1) * 4);
+                 o_bg = take((size_t)S * S), o_lr = take(S * 4), o_lc = take(S * 4), o_ls = take((c.max_steps + 1) * 4),
+                 o_rl = take(rew_lut.size() * 8);
     h->arena_bytes = off;
     hipError_t e = hipMalloc(&h->arena, off);
     if (e != hipSuccess) { delete h; return hip_fail(e, "hipMalloc(env arena)"); }
@@ -661,6 +687,8 @@ extern "C" int cm_env_create(const cm_env_cfg *cfg, cm_env_t *out) {
     d.status = (int32_t *)(base + o_st);
     d.base_grid = (const uint8_t *)(base + o_bg); d.lut_row = (const float *)(base + o_lr); d.lut_col = (const float *)(base + o_lc);
     d.lut_step = (const float *)(base + o_ls);
+    d.rew_lut = (const double *)(base + o_rl);
+    hipMemcpy(base + o_rl, rew_lut.data(), rew_lut.size() * 8, hipMemcpyHostToDevice);
     hipMemcpy(base + o_bg, walls.data(), walls.size(), hipMemcpyHostToDevice);
     hipMemcpy(base + o_lr, lut_row.data(), S * 4, hipMemcpyHostToDevice);
     hipMemcpy(base + o_lc, lut_col.data(), S * 4, hipMemcpyHostToDevice);
@@ -676,6 +704,7 @@ extern "C" int cm_env_create(const cm_env_cfg *cfg, cm_env_t *out) {
         if (const char *e = getenv("COMMARL_ENV_LPE")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) d.lpe = v; }
     }
     h->lds_bytes = (size_t)d.lds_env * (WAVE / d.lpe);
+    { const char *e = getenv("COMMARL_ENV_STOP"); d.stop = e ? atoi(e) : 0; }
     d.rcp_d = 1.0f / (float)d.d; d.rcp_W = 1.0f / (float)d.W; d.rcp_N = 1.0f / (float)d.N;
     d.rcp_WW = 1.0f / (float)(d.W * d.W); d.rcp_NN = 1.0f / (float)(d.N * d.N);
     e = hipDeviceSynchronize();

@@ -23,6 +23,7 @@ struct EnvDev {
     int scen, B, N, M, S, R, W, d, load, max_steps, mpl, L, rc2, channel, add_clock, n_empty, rng_mode, env_id_offset;
     int adj_const, ch_const;
     int lpe, lds_env;         // lanes per env (16/32/64) and LDS bytes per env
+    int stop;                 // diagnostic (COMMARL_ENV_STOP): return after phase `stop`; 0 = run everything
     float rcp_d, rcp_W, rcp_N, rcp_WW, rcp_NN;   // float reciprocals for the exact fast division in the emit loops
     float ploss, pgb, pbg;
     double cap_rew, step_cost, move_cost, penalty, lazy, revisit, final_reward;
@@ -43,6 +44,7 @@ struct EnvDev {
     const float *lut_row;     // [S]   obs row coordinate
     const float *lut_col;     // [S]
     const float *lut_step;    // [max_steps+1] clock
+    const double *rew_lut;    // count-indexed f64 reward terms (no f64 division on the device)
 };
 
 }  // namespace cm

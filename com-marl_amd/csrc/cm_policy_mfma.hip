@@ -31,6 +31,12 @@ constexpr int SE = 68;         // aligned ds_read_b128; the +4 skews rows across
 constexpr int MAX_ACT = 8;
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+// Workgroup barrier for LDS hand-offs only.  __syncthreads() also drains vmcnt(0), i.e. it would wait for the
+// NEXT layer's weight prefetch (global loads issued one layer ahead) at every phase boundary and expose the L2
+// latency ~13 times per kernel.  Here only the LDS counter is drained; the compiler still places the vmcnt wait
+// in front of the first use of a prefetched register.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // tanh(x) = 1 - 2 / (exp(2x) + 1) on the hardware exp2 / rcp units: ~8 instructions instead of the
 // ~40 of the libm-grade tanhf.  Absolute error <= 2e-7 over the whole range (measured against
 // double tanh in tests/test_hip_policy_parity.py), far inside the 1e-5 parity bar; saturates to
@@ -170,19 +176,19 @@ __global__ __launch_bounds__(TPB) void fwd_mfma_kernel(FwdArgs a, TrunkW tw, Pol
             X[(size_t)r * SX + f] = (r < rows && f < d) ? src[(size_t)r * d + f] : 0.0f;
         }
     }
-    __syncthreads();
+    lds_barrier();
     if (a.stop == 1) return;
     l_enc1.template run<true>(X, SX, bufA, SA, RT, wave, lane);
     Layer<EMB, EMB> l_sq;                               // 64x64 square layers: attention, then the GCN hops
     l_sq.load(tw.attn_wt, nullptr, EMB, wave, lane);
-    __syncthreads();
+    lds_barrier();
     if (a.stop == 2) return;
     l_enc2.template run<true>(bufA, SA, E, SE, RT, wave, lane);
-    __syncthreads();
+    lds_barrier();
     if (a.stop == 3) return;
     l_sq.template run<false>(E, SE, T, SE, RT, wave, lane);                                  // Q = E.Wa^T
     if (L > 0) l_sq.load(tw.gcn_w, nullptr, EMB, wave, lane);
-    __syncthreads();
+    lds_barrier();
     if (a.stop == 4) return;
     // ---- attention scores + softmax (VALU, N x N per env) ----
     for (int k = tid; k < envs * NN; k += TPB) {
@@ -197,7 +203,7 @@ __global__ __launch_bounds__(TPB) void fwd_mfma_kernel(FwdArgs a, TrunkW tw, Pol
         }
         M[(size_t)(e * N + i) * NP + j] = acc;
     }
-    __syncthreads();
+    lds_barrier();
     for (int r = tid; r < rows; r += TPB) {
         float *m = M + (size_t)r * NP;
         float mx = -INFINITY, sum = 0.0f;
@@ -205,7 +211,7 @@ __global__ __launch_bounds__(TPB) void fwd_mfma_kernel(FwdArgs a, TrunkW tw, Pol
         for (int j = 0; j < N; ++j) { const float ex = expf(m[j] - mx); m[j] = ex; sum += ex; }
         for (int j = 0; j < N; ++j) m[j] = m[j] / sum;
     }
-    __syncthreads();
+    lds_barrier();
     if (a.attn) {
         float *dst = a.attn + (size_t)s0 * NN;
         for (int k = tid; k < envs * NN; k += TPB) { const int r = k / N, j = k - r * N; dst[k] = M[(size_t)r * NP + j]; }
@@ -241,7 +247,7 @@ __global__ __launch_bounds__(TPB) void fwd_mfma_kernel(FwdArgs a, TrunkW tw, Pol
                 if (a.chan) v *= a.chan[((size_t)(s0 + e) * L + l) * NN + ij];
                 Amat[(size_t)r * NP + j] = v;
             }
-            __syncthreads();
+            lds_barrier();
             for (int r = tid; r < rows; r += TPB) {
                 float *ar = Amat + (size_t)r * NP;
                 float sum = 0.0f;
@@ -250,7 +256,7 @@ __global__ __launch_bounds__(TPB) void fwd_mfma_kernel(FwdArgs a, TrunkW tw, Pol
                 for (int j = 0; j < N; ++j) ar[j] = ar[j] / den;
             }
         }
-        __syncthreads();
+        lds_barrier();
         {
             const int o = tid & (EMB - 1), rg = tid >> 6;
             const float bv = tw.gcn_b ? tw.gcn_b[(size_t)l * EMB + o] : 0.0f;
@@ -274,13 +280,13 @@ __global__ __launch_bounds__(TPB) void fwd_mfma_kernel(FwdArgs a, TrunkW tw, Pol
                     }
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
     if (a.stop == 6) return;
     // ---- residual ----
     if (L == 0) {                                       // no hops: x = E (the hop epilogue adds the residual otherwise)
         for (int k = tid; k < rows * EMB; k += TPB) { const int r = k >> 6, o = k & 63; H[(size_t)r * SE + o] = E[(size_t)r * SE + o]; }
-        __syncthreads();
+        lds_barrier();
     }
 
     if (HEAD == 0) {
@@ -291,17 +297,17 @@ __global__ __launch_bounds__(TPB) void fwd_mfma_kernel(FwdArgs a, TrunkW tw, Pol
         l_h1.template run<true>(H, SE, bufA, SA, RT, wave, lane);
         Layer<H2, H3> l_h3;
         l_h3.load(ph.w3t, ph.b3, H2, wave, lane);
-        __syncthreads();
+        lds_barrier();
         l_h2.template run<true>(bufA, SA, T, SE, RT, wave, lane);
         const int A = ph.n_act;
         Layer<H3, 16> l_h4;                              // 32 -> n_act (<= 8) logits, zero-padded to one column tile
         l_h4.load(ph.w4t, ph.b4, H3, wave, lane, A);
-        __syncthreads();
+        lds_barrier();
         l_h3.template run<true>(T, SE, E, SE, RT, wave, lane);
-        __syncthreads();
+        lds_barrier();
         if (a.stop == 7) return;
         l_h4.template run<false>(E, SE, bufA, SA, RT, wave, lane);
-        __syncthreads();
+        lds_barrier();
         for (int r = tid; r < rows; r += TPB) {
             float lg[MAX_ACT], p[MAX_ACT];
             const float *x = bufA + (size_t)r * SA;
@@ -349,14 +355,14 @@ __global__ __launch_bounds__(TPB) void fwd_mfma_kernel(FwdArgs a, TrunkW tw, Pol
         Layer<EMB, DH> l_d1;
         l_d1.load(chd.w1t, chd.b1, EMB, wave, lane);
         l_d1.template run<true>(H, SE, T, SE, RT, wave, lane);
-        __syncthreads();
+        lds_barrier();
         for (int r = tid; r < rows; r += TPB) {
             const float *x = T + (size_t)r * SE;
             float acc = chd.b2 ? chd.b2[0] : 0.0f;
             for (int k = 0; k < DH; ++k) acc = fmaf(x[k], chd.w2t[k], acc);
             rs[r] = acc;
         }
-        __syncthreads();
+        lds_barrier();
         for (int e = tid; e < envs; e += TPB) {
             float v = 0.0f;
             for (int i = 0; i < N; ++i) v += rs[e * N + i];

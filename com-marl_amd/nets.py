@@ -430,7 +430,8 @@ class CommCategoricalMLPPolicy(CommBaseNet):
 
     @torch.no_grad()
     def act_device(self, obs, avail, dist_adj, channels, greedy=False, want_actions=True, want_probs=True,
-                   want_attn=True, out_actions=None, out_probs=None, out_attn=None, policy_step=None, step_base=None):
+                   want_attn=True, out_actions=None, out_probs=None, out_attn=None, policy_step=None, step_base=None,
+                   env_id_offset=None):
         """Fused forward on device tensors: obs [S,N*d]|[S,N,d]; avail/dist_adj/channels may be None
         (= all ones).  Returns (actions int32 [S,N], probs [S,N,A], attn [S,N,N]) as CUDA tensors."""
         dev = obs.device
@@ -453,7 +454,8 @@ class CommCategoricalMLPPolicy(CommBaseNet):
             L.check(L.lib().cm_policy_forward(
                 C.byref(w), S, L.ptr(obs), L.ptr(None if avail is None else avail.contiguous()),
                 L.ptr(None if dist_adj is None else dist_adj.contiguous()),
-                L.ptr(None if channels is None else channels.contiguous()), self.seed, self.env_id_offset,
+                L.ptr(None if channels is None else channels.contiguous()), self.seed,
+                self.env_id_offset if env_id_offset is None else int(env_id_offset),
                 policy_step & 0xFFFFFFFF, L.ptr(step_base), int(greedy), L.ptr(actions), L.ptr(probs), L.ptr(attn),
                 L.current_stream()), "cm_policy_forward")
         return actions, probs, attn

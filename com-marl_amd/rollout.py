@@ -16,10 +16,42 @@ import torch
 from . import _lib as L
 
 
+class _Parts:
+    """Facade over several GridEnvBatch shards that together form one batch (global env ids are
+    contiguous: shard k starts at the end of shard k-1)."""
+
+    def __init__(self, parts):
+        self.parts = parts
+        e0 = parts[0]
+        self.device, self.N, self.M, self.d, self.Lh = e0.device, e0.N, e0.M, e0.d, e0.Lh
+        self.adj_const, self.ch_const, self.scenario = e0.adj_const, e0.ch_const, e0.scenario
+        self.n_empty_cells, self.channels = e0.n_empty_cells, e0.channels
+        self.B = sum(p.B for p in parts)
+        self.bounds, lo = [], 0
+        for p in parts:
+            assert (p.N, p.d, p.Lh, p.scenario) == (e0.N, e0.d, e0.Lh, e0.scenario) and p.device == e0.device
+            assert p.cfg.env_id_offset == e0.cfg.env_id_offset + lo, "shards must cover contiguous global env ids"
+            self.bounds.append((lo, lo + p.B))
+            lo += p.B
+
+    def check_status(self):
+        for p in self.parts:
+            p.check_status()
+
+
 class RolloutEngine:
     def __init__(self, env, policy, horizon, store_attn=True, store_probs=True):
-        """env: envs.GridEnvBatch; policy: nets.CommCategoricalMLPPolicy on the same device."""
+        """env: envs.GridEnvBatch, or a list of shards of one batch (then every shard runs its own
+        policy -> env chain on its own HIP stream: the chains are independent, so kernels of different
+        shards overlap and their phases drift apart instead of contending in lockstep).
+        policy: nets.CommCategoricalMLPPolicy on the same device."""
+        if isinstance(env, (list, tuple)):
+            env = _Parts(list(env)) if len(env) > 1 else env[0]
         self.env, self.policy, self.H = env, policy, int(horizon)
+        self.parts = env.parts if isinstance(env, _Parts) else [env]
+        self.bounds = env.bounds if isinstance(env, _Parts) else [(0, env.B)]
+        self.streams = [torch.cuda.Stream(device=env.device) for _ in self.parts] if len(self.parts) > 1 else [None]
+        self.id0 = self.parts[0].cfg.env_id_offset
         dev, B, N, M, d, Lh = env.device, env.B, env.N, max(env.M, 1), env.d, env.Lh
         A = policy._action_dim
         H = self.H
@@ -44,40 +76,64 @@ class RolloutEngine:
         self.t = 0
 
     # ------------------------------------------------------------------------------------------
-    def _out(self, t):
-        o = dict(obs=self.obs[t + 1], reward=self.reward[t], reward_f64=self.reward64[t], done=self.done[t],
-                 details=self.details[t], success=self.success[t], path_len=self.path_len[t])
+    def _out(self, t, lo, hi):
+        o = dict(obs=self.obs[t + 1][lo:hi], reward=self.reward[t][lo:hi], reward_f64=self.reward64[t][lo:hi],
+                 done=self.done[t][lo:hi], details=self.details[t][lo:hi], success=self.success[t][lo:hi],
+                 path_len=self.path_len[t][lo:hi])
         if self.prey_alive is not None:
-            o["prey_alive"] = self.prey_alive[t]
+            o["prey_alive"] = self.prey_alive[t][lo:hi]
         if self.dist_adj is not None:
-            o["dist_adj"] = self.dist_adj[t + 1]
+            o["dist_adj"] = self.dist_adj[t + 1][lo:hi]
         if self.channels is not None:
-            o["channels"] = self.channels[t + 1]
+            o["channels"] = self.channels[t + 1][lo:hi]
         return o
 
     def reset(self):
         """VecEnvExecutor.reset: every env restarts; slot 0 receives the first observation."""
-        o = dict(obs=self.obs[0])
-        if self.dist_adj is not None:
-            o["dist_adj"] = self.dist_adj[0]
-        if self.channels is not None:
-            o["channels"] = self.channels[0]
-        self.env.reset_all(out=o)
+        for part, (lo, hi) in zip(self.parts, self.bounds):
+            o = dict(obs=self.obs[0][lo:hi])
+            if self.dist_adj is not None:
+                o["dist_adj"] = self.dist_adj[0][lo:hi]
+            if self.channels is not None:
+                o["channels"] = self.channels[0][lo:hi]
+            part.reset_all(out=o)
         self.t = 0
 
-    def step(self, t, greedy=False):
-        """Slot t -> t+1 (asynchronous)."""
-        B = self.env.B
+    def _step_part(self, k, t, greedy):
+        part, (lo, hi) = self.parts[k], self.bounds[k]
+        nb = hi - lo
         self.policy.act_device(
-            self.obs[t].view(B, -1), None,
-            None if self.dist_adj is None else self.dist_adj[t],
-            None if self.channels is None else self.channels[t],
-            greedy=greedy, out_actions=self.actions[t],
-            out_probs=None if self.probs is None else self.probs[t],
-            out_attn=None if self.attn is None else self.attn[t],
+            self.obs[t][lo:hi].view(nb, -1), None,
+            None if self.dist_adj is None else self.dist_adj[t][lo:hi],
+            None if self.channels is None else self.channels[t][lo:hi],
+            greedy=greedy, out_actions=self.actions[t][lo:hi],
+            out_probs=None if self.probs is None else self.probs[t][lo:hi],
+            out_attn=None if self.attn is None else self.attn[t][lo:hi],
             want_probs=self.probs is not None, want_attn=self.attn is not None,
-            policy_step=t, step_base=self.step_base)
-        self.env.step_device(self.actions[t], out=self._out(t))
+            policy_step=t, step_base=self.step_base, env_id_offset=self.id0 + lo)
+        part.step_device(self.actions[t][lo:hi], out=self._out(t, lo, hi))
+
+    def step(self, t, greedy=False):
+        """Slot t -> t+1 (asynchronous).  With several shards each chain goes to its own stream; call
+        join() (or run_chunk) before the host or another stream consumes the slot."""
+        if len(self.parts) == 1:
+            self._step_part(0, t, greedy)
+            return
+        for k, st in enumerate(self.streams):
+            with torch.cuda.stream(st):
+                self._step_part(k, t, greedy)
+
+    def fork(self):
+        cur = torch.cuda.current_stream(self.env.device)
+        for st in self.streams:
+            if st is not None:
+                st.wait_stream(cur)
+
+    def join(self):
+        cur = torch.cuda.current_stream(self.env.device)
+        for st in self.streams:
+            if st is not None:
+                cur.wait_stream(st)
 
     def _wrap(self):
         """Carry the last slot of the previous chunk into slot 0 (what `obses = next_obses` does)."""
@@ -90,20 +146,26 @@ class RolloutEngine:
     def run_chunk(self, use_graph=True):
         """H steps filling every slot; with use_graph the chunk is one hipGraph replay."""
         if not use_graph:
+            self.fork()
             for t in range(self.H):
                 self.step(t)
+            self.join()
             self.step_base.add_(self.H)
             self._wrap()
             return
         g = self._graphs.get("chunk")
         if g is None:
             # warm-up outside capture: first-call attribute setup + weight pack must not be captured
+            self.fork()
             self.step(0)
+            self.join()
             torch.cuda.synchronize(self.env.device)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):   # NCCL's watchdog thread may touch HIP during capture
+                self.fork()
                 for t in range(self.H):
                     self.step(t)
+                self.join()
                 self.step_base.add_(self.H)
                 self._wrap()
             self._graphs["chunk"] = g

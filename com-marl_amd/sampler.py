@@ -171,6 +171,7 @@ class CentralizedMAOnPolicyVectorizedSampler:
             t1 = min(t + chunk, horizon)
             for k in range(t, t1):
                 eng.step(k)
+            eng.join()
             # stop rule on device: first step at which cumulative completed samples >= batch_size
             done_samples = eng.path_len[:t1].sum(dim=1, dtype=torch.int64).cumsum(0) * N
             hit = torch.nonzero(done_samples >= batch_size)

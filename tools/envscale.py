@@ -25,6 +25,10 @@ if len(sys.argv) > 1:
         t = timeit(lambda: env.step_device(act))
         env.check_status()
         print(f"{cfgname} LPE={os.environ.get('COMMARL_ENV_LPE','auto')} B={B}: env step {t:.1f} us", flush=True)
+elif os.environ.get("PHASES"):
+    for k in (1, 2, 3, 4, 5, 6, 7, 0):
+        print("stop", k, flush=True)
+        subprocess.run([sys.executable, __file__, "child", "pp_map10", "4096"], env=dict(os.environ, COMMARL_ENV_STOP=str(k)))
 else:
     for cfg, Bs, lpes in (("pp_map10", "1024,4096,16384", ("16", "32", "64")), ("co_map20", "512,2048,8192", ("32", "64")),
                           ("pp_map30", "256,1024,4096", ("64",)), ("co_map30", "256,1024,4096", ("64",))):
