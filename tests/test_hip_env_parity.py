@@ -137,3 +137,19 @@ def test_unsupported_config_is_refused(hip):
         hip.HipEnv(O.make_cfg("pp", 2, 4, 10, 1, n_preys=4, load=5))
     with pytest.raises(CommarlError):
         hip.HipEnv(O.make_cfg("pp", 2, 4, 40, 1, n_preys=4))     # grid side > 32
+
+
+def test_ragged_batch_sizes_and_empty_calls(hip):
+    """Batch sizes that do not fill the last wave's env groups (4 envs per wave at N=4), and S=0 calls."""
+    for B in (1, 3, 7, 61):
+        _lockstep(dict(scenario="pp", n_envs=B, n_agents=4, n_preys=4, grid=10, rsen=1, load=2, max_steps=11), steps=25,
+                  hip=hip, check_every=1)
+    _lockstep(dict(scenario="co", n_envs=5, n_agents=6, grid=10, rsen=1, max_steps=400, max_path_length=9), steps=20,
+              hip=hip, check_every=1)
+    import ctypes as C
+    from com_marl_amd import _lib as L
+    w = L.PolicyWeights()
+    assert L.lib().cm_policy_forward(C.byref(w), 0, 1, None, None, None, 0, 0, 0, None, 0, None, None, None, None) == 0
+    assert L.lib().cm_gae(0, 5, 1, 1, None, 0.99, 0.97, 0, 1e-8, 1, None) == 0
+    assert L.lib().cm_masked_agg_forward(0, 4, 64, 1, None, None, 0, 1, None, 1, None) == 0
+    assert L.lib().cm_linear_wgrad(0, 4, 4, 1, 1, 1, None, None) == 0
