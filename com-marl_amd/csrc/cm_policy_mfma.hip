@@ -141,12 +141,127 @@ struct Layer {
     }
 };
 
+// Reductions over a 16-lane DPP row (all 16 lanes receive the result): quad swaps, then row_half_mirror and
+// row_mirror.  Pure VALU+DPP - __shfl_xor lowers to ds_bpermute (an LDS-crossbar round trip per step), which made
+// a 64-lane shuffle reduction cost ~1 us per matrix row.
+__device__ __forceinline__ float dpp_f(float v, int ctrl_sel) {
+    const int x = __float_as_int(v);
+    int y;
+    switch (ctrl_sel) {
+    case 0: y = __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false); break;    // quad_perm [1,0,3,2]
+    case 1: y = __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false); break;    // quad_perm [2,3,0,1]
+    case 2: y = __builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, 0xF, false); break;   // row_half_mirror
+    default: y = __builtin_amdgcn_update_dpp(x, x, 0x140, 0xF, 0xF, false); break;  // row_mirror
+    }
+    return __int_as_float(y);
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_f(v, 0)); v = fmaxf(v, dpp_f(v, 1)); v = fmaxf(v, dpp_f(v, 2)); v = fmaxf(v, dpp_f(v, 3));
+    return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f(v, 0); v += dpp_f(v, 1); v += dpp_f(v, 2); v += dpp_f(v, 3);
+    return v;
+}
+
+// Per-env N x N products on the matrix cores (used when N >= 16; the VALU forms below are kept for small
+// teams where an N x N tile would be mostly padding: N < 32).
+// scores[e][i][j] = sum_k Q[e*N+i][k] * K[e*N+j][k]   (K = 64): 16x16 output tiles dealt round-robin to waves;
+// both operands are 16-byte LDS reads of one activation row.
+__device__ __forceinline__ void scores_mfma(const float *Q, const float *K, float *M, int N, int NP, int envs, int wave, int lane) {
+    const int c = lane & 15, g = lane >> 4, NT = (N + 15) >> 4, per_env = NT * NT;
+    for (int t = wave; t < envs * per_env; t += 4) {
+        const int e = t / per_env, rc = t - e * per_env, rt = rc / NT, ct = rc - rt * NT;
+        const int ra = min(rt * 16 + c, N - 1), rb = min(ct * 16 + c, N - 1);          // clamped rows: results masked below
+        const float4 *pa = reinterpret_cast<const float4 *>(Q + (size_t)(e * N + ra) * SE + 4 * g);
+        const float4 *pb = reinterpret_cast<const float4 *>(K + (size_t)(e * N + rb) * SE + 4 * g);
+        float4 av[EMB / 16], bw[EMB / 16];
+#pragma unroll
+        for (int kq = 0; kq < EMB / 16; ++kq) { av[kq] = pa[4 * kq]; bw[kq] = pb[4 * kq]; }
+        v4f acc = (v4f){ 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+        for (int kq = 0; kq < EMB / 16; ++kq) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kq].x, bw[kq].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kq].y, bw[kq].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kq].z, bw[kq].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kq].w, bw[kq].w, acc, 0, 0, 0);
+        }
+        const int j = ct * 16 + c;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = rt * 16 + 4 * g + r;
+            if (i < N && j < N) M[(size_t)(e * N + i) * NP + j] = acc[r];
+        }
+    }
+}
+
+// H'[e*N+i][o] = tanh(sum_j A[e*N+i][j] * HW[e*N+j][o] + b[o]) (+ E residual on the last hop).  Wave w owns
+// output columns 16w..16w+15: its B fragment (a K x 16 slab of HW, K = N padded to 16) is loaded once per env
+// and reused by every row tile; A rows are 16-byte reads of the zero-padded [rows][NPA] tile.
+template <int MAXKS>
+__device__ __forceinline__ void agg_mfma(const float *A, int NPA, const float *HW, const float *bias, const float *Eres,
+                                         float *Hout, int N, int envs, int wave, int lane) {
+    const int c = lane & 15, g = lane >> 4, NT = (N + 15) >> 4, KQ = NT;            // k-steps of 16
+    const int col = wave * 16 + c;
+    const float bv = bias ? bias[col] : 0.0f;
+    for (int e = 0; e < envs; ++e) {
+        float b[MAXKS];
+#pragma unroll
+        for (int kk = 0; kk < MAXKS; ++kk) {
+            const int k = 16 * (kk >> 2) + 4 * g + (kk & 3);
+            b[kk] = (kk < 4 * KQ && k < N) ? HW[(size_t)(e * N + k) * SE + col] : 0.0f;
+        }
+        for (int rt = 0; rt < NT; rt += 2) {            // two row tiles in flight: independent accumulator chains
+            const bool hasB = rt + 1 < NT;
+            const int ra = min(rt * 16 + c, N - 1), rb = min((hasB ? rt + 1 : rt) * 16 + c, N - 1);
+            const float4 *pa = reinterpret_cast<const float4 *>(A + (size_t)(e * N + ra) * NPA + 4 * g);
+            const float4 *pb = reinterpret_cast<const float4 *>(A + (size_t)(e * N + rb) * NPA + 4 * g);
+            float4 xa[MAXKS / 4], xb[MAXKS / 4];
+#pragma unroll
+            for (int kq = 0; kq < MAXKS / 4; ++kq) {    // branch-free: steps past KQ re-read step KQ-1 and meet b == 0
+                const int kc = kq < KQ ? kq : KQ - 1;
+                xa[kq] = pa[4 * kc]; xb[kq] = pb[4 * kc];
+            }
+            v4f acc0 = (v4f){ 0.f, 0.f, 0.f, 0.f }, acc1 = (v4f){ 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+            for (int kq = 0; kq < MAXKS / 4; ++kq) {
+                if (kq < KQ) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[kq].x, b[4 * kq + 0], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[kq].x, b[4 * kq + 0], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[kq].y, b[4 * kq + 1], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[kq].y, b[4 * kq + 1], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[kq].z, b[4 * kq + 2], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[kq].z, b[4 * kq + 2], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[kq].w, b[4 * kq + 3], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[kq].w, b[4 * kq + 3], acc1, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i0 = rt * 16 + 4 * g + r, i1 = i0 + 16;
+                if (i0 < N) {
+                    const size_t o = (size_t)(e * N + i0) * SE + col;
+                    const float hv = fast_tanh(acc0[r] + bv);
+                    Hout[o] = Eres ? Eres[o] + hv : hv;
+                }
+                if (hasB && i1 < N) {
+                    const size_t o = (size_t)(e * N + i1) * SE + col;
+                    const float hv = fast_tanh(acc1[r] + bv);
+                    Hout[o] = Eres ? Eres[o] + hv : hv;
+                }
+            }
+        }
+    }
+}
+
 __host__ __device__ inline size_t lds_floats(int rows_pad, int epb, int N) {
     const int NP = N | 1;
     return (size_t)rows_pad * (SA + 3 * SE) + (size_t)epb * N * NP + rows_pad;
 }
 
-template <int HEAD, int KPAD>   // HEAD 0 = policy, 1 = critic; KPAD = obs dim rounded up to 16
+// HEAD 0 = policy, 1 = critic; KPAD = obs dim rounded up to 16; MAXMK = mask elements per thread held in
+// registers across a hop's MFMAs (0 for small teams: N*N <= MAXMK*256)
+template <int HEAD, int KPAD, int MAXMK>
 __global__ __launch_bounds__(TPB) void fwd_mfma_kernel(FwdArgs a, TrunkW tw, PolHead ph, CritHead chd) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -190,39 +305,123 @@ __global__ __launch_bounds__(TPB) void fwd_mfma_kernel(FwdArgs a, TrunkW tw, Pol
     if (L > 0) l_sq.load(tw.gcn_w, nullptr, EMB, wave, lane);
     lds_barrier();
     if (a.stop == 4) return;
-    // ---- attention scores + softmax (VALU, N x N per env) ----
-    for (int k = tid; k < envs * NN; k += TPB) {
-        const int e = k / NN, ij = k - e * NN, i = ij / N, j = ij - i * N;
-        const float4 *q = reinterpret_cast<const float4 *>(T + (size_t)(e * N + i) * SE);
-        const float4 *c = reinterpret_cast<const float4 *>(E + (size_t)(e * N + j) * SE);
-        float acc = 0.0f;
-#pragma unroll
-        for (int kk = 0; kk < EMB / 4; ++kk) {
-            const float4 x = q[kk], y = c[kk];
-            acc = fmaf(x.x, y.x, acc); acc = fmaf(x.y, y.y, acc); acc = fmaf(x.z, y.z, acc); acc = fmaf(x.w, y.w, acc);
+    // ---- attention scores + softmax: N x N per env ----
+    const bool big = MAXMK > 0;                         // matrix-core path for the N x N products (N >= 16)
+    if (big) {
+        scores_mfma(T, E, M, N, NP, envs, wave, lane);
+        lds_barrier();
+        if (a.stop == 41) return;
+        for (int r0 = 0; r0 < rows; r0 += TPB / 16) {   // 16 lanes per matrix row, DPP row reductions
+            const int r = min(r0 + (tid >> 4), rows - 1), sl = tid & 15;
+            float *m = M + (size_t)r * NP;
+            float mx = -INFINITY;
+            for (int j = sl; j < N; j += 16) mx = fmaxf(mx, m[j]);
+            mx = row16_max(mx);
+            float sum = 0.0f;
+            for (int j = sl; j < N; j += 16) { const float ex = expf(m[j] - mx); sum += ex; if (r0 + (tid >> 4) < rows) m[j] = ex; }
+            sum = row16_sum(sum);
+            if (r0 + (tid >> 4) < rows)
+                for (int j = sl; j < N; j += 16) m[j] = m[j] / sum;
         }
-        M[(size_t)(e * N + i) * NP + j] = acc;
+    } else {
+        for (int k = tid; k < envs * NN; k += TPB) {
+            const int e = k / NN, ij = k - e * NN, i = ij / N, j = ij - i * N;
+            const float4 *q = reinterpret_cast<const float4 *>(T + (size_t)(e * N + i) * SE);
+            const float4 *c = reinterpret_cast<const float4 *>(E + (size_t)(e * N + j) * SE);
+            float acc = 0.0f;
+#pragma unroll
+            for (int kk = 0; kk < EMB / 4; ++kk) {
+                const float4 x = q[kk], y = c[kk];
+                acc = fmaf(x.x, y.x, acc); acc = fmaf(x.y, y.y, acc); acc = fmaf(x.z, y.z, acc); acc = fmaf(x.w, y.w, acc);
+            }
+            M[(size_t)(e * N + i) * NP + j] = acc;
+        }
+        lds_barrier();
+        for (int r = tid; r < rows; r += TPB) {
+            float *m = M + (size_t)r * NP;
+            float mx = -INFINITY, sum = 0.0f;
+            for (int j = 0; j < N; ++j) mx = fmaxf(mx, m[j]);
+            for (int j = 0; j < N; ++j) { const float ex = expf(m[j] - mx); m[j] = ex; sum += ex; }
+            for (int j = 0; j < N; ++j) m[j] = m[j] / sum;
+        }
     }
     lds_barrier();
-    for (int r = tid; r < rows; r += TPB) {
-        float *m = M + (size_t)r * NP;
-        float mx = -INFINITY, sum = 0.0f;
-        for (int j = 0; j < N; ++j) mx = fmaxf(mx, m[j]);
-        for (int j = 0; j < N; ++j) { const float ex = expf(m[j] - mx); m[j] = ex; sum += ex; }
-        for (int j = 0; j < N; ++j) m[j] = m[j] / sum;
-    }
-    lds_barrier();
+    if (a.stop == 42) return;
     if (a.attn) {
         float *dst = a.attn + (size_t)s0 * NN;
-        for (int k = tid; k < envs * NN; k += TPB) { const int r = k / N, j = k - r * N; dst[k] = M[(size_t)r * NP + j]; }
+        if (big) {                                      // 16 lanes per row: no per-element division
+            for (int r = tid >> 4; r < rows; r += TPB / 16)
+                for (int j = tid & 15; j < N; j += 16) dst[(size_t)r * N + j] = M[(size_t)r * NP + j];
+        } else {
+            for (int k = tid; k < envs * NN; k += TPB) { const int r = k / N, j = k - r * N; dst[k] = M[(size_t)r * NP + j]; }
+        }
     }
     if (a.stop == 5) return;
     // ---- L GCN hops: HW on the matrix cores, masked aggregation on the VALU ----
     float *Amat = bufA;                                 // [rows][NP]
     for (int l = 0; l < L; ++l) {
         const float *Hin = (l == 0) ? E : H;
+        // big teams: the hop's mask product Range*Chan_l is fetched (coalesced) BEFORE the H.Wg MFMAs so the HBM
+        // latency hides under them; registers hold it until the A tile is written
+        // 16-lane group gq = tid>>4 owns matrix rows gq, gq+16, ...; lane sl = tid&15 owns columns sl, sl+16, ...
+        // mk[rb*JB + jb] is element (row rb*16+gq, column jb*16+sl): no divisions anywhere in the mask path
+        constexpr int JB = MAXMK == 25 ? 5 : 8;                             // column blocks per row (N <= 16*JB)
+        float mk[MAXMK > 0 ? MAXMK : 1];
+        const bool masked = a.adj || a.chan;
+        if (MAXMK > 0 && masked) {
+            const int gq = tid >> 4, sl = tid & 15;
+#pragma unroll
+            for (int q = 0; q < MAXMK; ++q) {
+                const int r = (q / JB) * 16 + gq, j = (q % JB) * 16 + sl;
+                float v = 1.0f;
+                if (r < rows && j < N) {
+                    const int e = envs == 1 ? 0 : r / N, i = r - e * N;
+                    const size_t off = (size_t)i * N + j;
+                    if (a.adj) v = a.adj[(size_t)(s0 + e) * NN + off];
+                    if (a.chan) v *= a.chan[((size_t)(s0 + e) * L + l) * NN + off];
+                }
+                mk[q] = v;
+            }
+        }
         l_sq.template run<false>(Hin, SE, T, SE, RT, wave, lane);                              // H.Wg_l
+        if (a.stop == 61 + l) return;
         if (l + 1 < L) l_sq.load(tw.gcn_w + (size_t)(l + 1) * EMB * EMB, nullptr, EMB, wave, lane);
+        if (MAXMK > 0 && big) {
+            // masked + renormalised rows of A, one wave per row (coalesced mask reads along j), written into the
+            // zero-padded [rows][NPA] tile the aggregation MFMA reads with 16-byte loads
+            const int NPA = (((N + 15) >> 4) << 4) + 4;
+            {   // A row = M row * mask, renormalised: 16 lanes per row, DPP row sum, one pass
+                const int gq = tid >> 4, sl = tid & 15;
+#pragma unroll
+                for (int rb = 0; rb < MAXMK / JB; ++rb) {
+                    const int r = rb * 16 + gq;
+                    if (rb * 16 < rows) {               // uniform: every group of the block shares rb
+                        const bool live = r < rows;
+                        const float *mr = M + (size_t)(live ? r : 0) * NP;
+                        float v[JB];
+                        float sum = 0.0f;
+#pragma unroll
+                        for (int jb = 0; jb < JB; ++jb) {
+                            const int j = jb * 16 + sl;
+                            v[jb] = (live && j < N) ? mr[j] * (masked ? mk[rb * JB + jb] : 1.0f) : 0.0f;
+                            sum += v[jb];
+                        }
+                        const float den = row16_sum(sum) + 1e-12f;
+                        if (live) {
+                            float *ar = Amat + (size_t)r * NPA;
+#pragma unroll
+                            for (int jb = 0; jb < JB; ++jb) { const int j = jb * 16 + sl; if (j < NPA) ar[j] = j < N ? v[jb] / den : 0.0f; }
+                        }
+                    }
+                }
+            }
+            lds_barrier();
+            if (a.stop == 51 + l) return;
+            agg_mfma<32>(Amat, NPA, T, tw.gcn_b ? tw.gcn_b + (size_t)l * EMB : nullptr,
+                         (l == L - 1 && !a.no_residual) ? E : nullptr, H, N, envs, wave, lane);
+            lds_barrier();
+            continue;
+        }
         if (N <= 16) {
             // small teams: one thread builds its whole masked + renormalised row (no intermediate barrier)
             for (int r = tid; r < rows; r += TPB) {
@@ -378,7 +577,7 @@ static int pick_epb(int N) {
     return e > 0 ? e : 1;
 }
 
-template <int HEAD, int KPAD>
+template <int HEAD, int KPAD, int MAXMK>
 static int launch(FwdArgs a, const TrunkW &tw, const PolHead &ph, const CritHead &chd, void *stream) {
     a.EPB = pick_epb(a.N);
     const int rows_cap = (a.EPB * a.N + 15) & ~15;
@@ -386,12 +585,12 @@ static int launch(FwdArgs a, const TrunkW &tw, const PolHead &ph, const CritHead
     if (lds > 160 * 1024) return set_error(CM_ERR_ARG, "policy forward: n_agents too large for the 160 KB LDS tile");
     static bool attr_set = false;
     if (!attr_set) {
-        CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fwd_mfma_kernel<HEAD, KPAD>),
+        CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fwd_mfma_kernel<HEAD, KPAD, MAXMK>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     const int blocks = (a.S + a.EPB - 1) / a.EPB;
-    hipLaunchKernelGGL((fwd_mfma_kernel<HEAD, KPAD>), dim3(blocks), dim3(TPB), lds, (hipStream_t)stream, a, tw, ph, chd);
+    hipLaunchKernelGGL((fwd_mfma_kernel<HEAD, KPAD, MAXMK>), dim3(blocks), dim3(TPB), lds, (hipStream_t)stream, a, tw, ph, chd);
     CM_HIP(hipGetLastError());
     return CM_OK;
 }
@@ -399,10 +598,17 @@ static int launch(FwdArgs a, const TrunkW &tw, const PolHead &ph, const CritHead
 template <int HEAD>
 static int dispatch(const FwdArgs &a, const TrunkW &tw, const PolHead &ph, const CritHead &chd, void *stream) {
     const int kpad = (a.d + 15) & ~15;
+    if (a.N > 128) return 1;             // N x N MFMA tiles are built for teams of up to 128 agents
+    const int nn = a.N * a.N;
+    // N x N products on MFMA from N = 32 up (measured: at N = 24 the padded 32 x 32 tiles lose to the VALU form)
+    const int mk = a.N < 32 ? 0 : (a.N <= 80 ? 25 : 64);    // (row blocks) x (column blocks) of 16
+    (void)nn;
+#define CM_FWD(K) (mk == 0 ? launch<HEAD, K, 0>(a, tw, ph, chd, stream) \
+                   : mk == 25 ? launch<HEAD, K, 25>(a, tw, ph, chd, stream) : launch<HEAD, K, 64>(a, tw, ph, chd, stream))
     switch (kpad) {      // obs dims of the reference scenarios: PP sen1 21, CO sen1 29, PP sen2 53, CO sen2 77 (+clock 78)
-    case 32: return launch<HEAD, 32>(a, tw, ph, chd, stream);
-    case 64: return launch<HEAD, 64>(a, tw, ph, chd, stream);
-    case 80: return launch<HEAD, 80>(a, tw, ph, chd, stream);
+    case 32: return CM_FWD(32);
+    case 64: return CM_FWD(64);
+    case 80: return CM_FWD(80);
     default: return 1;   // caller falls back to the generic VALU kernel
     }
 }
