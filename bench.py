@@ -258,11 +258,14 @@ def main():
                                   bytes_per_env_step=b_env + b_pol))
 
     out = {
-        "metric": "env-steps/sec (whole job), rollout = fused policy forward + sample + env step with auto-reset",
+        # BASELINE.json's metric for the headline config; rollout = fused policy forward + sample + env step + auto-reset
+        "metric": ("env-steps/sec (whole node), PredatorPrey M=10 N=4, 4096 envs at 1/2/4/8 GPUs" if args.config == "pp_map10"
+                   else f"env-steps/sec (whole node), {args.config}"),
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 (policy GEMMs) + int32/u8 (grid state)", "data": "synthetic",
-        "config": {"workload": c["label"], "envs_per_gpu": B, "total_envs": B * world, "n_agents": c["n_agents"],
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": c["label"] + "; one step = fused policy forward + sample + env step with auto-reset, "
+                               "trajectory written to HBM", "envs_per_gpu": B, "total_envs": B * world, "n_agents": c["n_agents"],
                    "obs_dim": env.d, "graph_chunk": 0 if args.no_graph else G, "streams": ns,
                    "parallelism": f"env-sharded x{world} (no data-path collective in the rollout)"},
         "roofline": roofline,
