@@ -103,7 +103,7 @@ class PathBatch(Sequence):
             dist_adjs=adj, channels=ch, attentions=attn,
             ave_degs=ave_deg, diameters=np.full(n, N if h["dist_adj"] is None else 0),
             ave_trputs=np.full(n, env.n_empty_cells if not pp else 0),
-            success=h["success"][s + n - 1].copy(),                       # [n_envs], read when the path ended (:194)
+            success=h["success"][s + n - 1].astype(np.int64),             # [n_envs], read when the path ended (:194)
             agent_infos=dict(action_probs=probs, attention_weights=attn),
             env_infos=dict(prey_alive=h["prey_alive"][sl, b].astype(bool)) if h["prey_alive"] is not None else {})
         return path

@@ -524,12 +524,19 @@ def record_ppo_step(seed=11):
     sampler = ns.ReferenceSampler(algo, Shell(env), n_envs=1)
     sampler.start_worker()
     paths = sampler.obtain_samples(0, batch_size=9 * 12 * 4)
+    # the sampler's path-dict contract: key -> (shape, dtype) of one reference path
+    def _desc(v):
+        if isinstance(v, dict):
+            return {k: _desc(x) for k, x in v.items()}
+        a = np.asarray(v)
+        return [list(a.shape), str(a.dtype)]
+    path_contract = json.dumps({k: _desc(v) for k, v in paths[0].items()})
     # make the batch ragged (random-policy episodes all run to the time limit): keep a prefix of two paths
     for i, n in ((1, 5), (4, 9)):
         for k, v in list(paths[i].items()):
             if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == 12 and k != 'success':
                 paths[i][k] = v[:n]
-    out = {}
+    out = {'path_contract': np.array(path_contract)}
     for name, p in policy.state_dict().items():
         out['pol0.' + name] = p.clone().numpy()
     for name, p in critic.state_dict().items():
