@@ -28,7 +28,8 @@ if len(sys.argv) > 1:
 elif os.environ.get("PHASES"):
     for k in (1, 2, 3, 4, 5, 6, 7, 0):
         print("stop", k, flush=True)
-        subprocess.run([sys.executable, __file__, "child", "pp_map10", "4096"], env=dict(os.environ, COMMARL_ENV_STOP=str(k)))
+        subprocess.run([sys.executable, __file__, "child", os.environ.get("CFG", "pp_map10"), os.environ.get("BS", "4096")],
+                       env=dict(os.environ, COMMARL_ENV_STOP=str(k)))
 else:
     for cfg, Bs, lpes in (("pp_map10", "1024,4096,16384", ("16", "32", "64")), ("co_map20", "512,2048,8192", ("32", "64")),
                           ("pp_map30", "256,1024,4096", ("64",)), ("co_map30", "256,1024,4096", ("64",))):
