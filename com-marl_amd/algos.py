@@ -204,6 +204,60 @@ class CentralizedMAPPO:
         ent = -(p_new * torch.log(p_new)).sum(-1).mean(-1).mean()
         return float(kl), float(ent)
 
+    def _log_performance(self, itr, paths, returns, valids):
+        """The progress.csv columns of centralized_ma_ppo.py:286-366 (per-path sums -> means over paths).
+        With a PathBatch everything is reduced on the device and one small vector comes to the host."""
+        N = self.policy._n_agents
+        if isinstance(paths, PathBatch):
+            e, dev = paths.engine, self._dev()
+            lens = paths.length
+            P, T = lens.numel(), int(lens.max().item())
+            tau = torch.arange(T, device=dev)
+            valid = tau[None, :] < lens[:, None]
+            t_idx = (paths.start[:, None] + tau[None, :]).clamp_(max=e.reward64.shape[0] - 1)
+            b_idx = paths.env_idx[:, None].expand(P, T)
+            rew = torch.where(valid, e.reward64[t_idx, b_idx], torch.zeros((), dtype=torch.float64, device=dev))
+            undisc = rew.sum(1)                                                      # np.sum(path_rewards), f64
+            det = (e.details[t_idx, b_idx].to(torch.float64) * valid[..., None]).sum(1)   # [P,6]
+            succ = e.success[paths.start + lens - 1, paths.env_idx].to(torch.float64)
+            if e.dist_adj is not None:
+                deg = (e.dist_adj[t_idx, b_idx].sum(-1).mean(-1).to(torch.float64) * valid).sum(1) / lens
+                diam = torch.zeros(P, dtype=torch.float64, device=dev)               # get_graph: diameter 0 (:234)
+            else:
+                deg = torch.full((P,), float(N), dtype=torch.float64, device=dev)
+                diam = deg.clone()
+            pp = e.env.scenario == "pp"
+            nA = float(N)
+            cap = det[:, 0] if pp else det[:, 0] / nA
+            pen = det[:, 2] if pp else det[:, 2] / nA
+            var2 = torch.zeros_like(cap) if pp else det[:, 3] / nA
+            cols = torch.stack([undisc, returns[:, 0].to(torch.float64), succ, cap, lens.to(torch.float64),
+                                det[:, 1] / nA, pen, det[:, 4] / nA, var2, deg, diam])
+            means = cols.mean(1).tolist()
+            std, mx, mn = float(undisc.std(unbiased=False)), float(undisc.max()), float(undisc.min())
+            trput = float(e.env.n_empty_cells if not pp else 0)
+            undisc_list = undisc.tolist()
+        else:
+            def col(f):
+                return [f(p) for p in paths]
+            dsum = lambda k: col(lambda p: float(np.sum([d[k] for d in p['rewards_details']])))   # noqa: E731
+            undisc_list = col(lambda p: float(np.sum(np.asarray(p['rewards']))))
+            means = [np.mean(undisc_list), float(returns[:, 0].to(torch.float64).mean()),
+                     np.mean(col(lambda p: np.mean(p['success']))), np.mean(dsum('capture_cnt')),
+                     np.mean(dsum('step_cnt')), np.mean(dsum('move_cnt')), np.mean(dsum('penalty_cnt')),
+                     np.mean(dsum('variable')), np.mean(dsum('vars2')),
+                     np.mean(col(lambda p: np.mean(p['ave_degs']))), np.mean(col(lambda p: np.mean(p['diameters'])))]
+            std, mx, mn = float(np.std(undisc_list)), float(np.max(undisc_list)), float(np.min(undisc_list))
+            trput = float(np.mean(col(lambda p: np.mean(p['ave_trputs']))))
+            P = len(paths)
+        self.episode_reward_mean.extend(undisc_list)
+        keys = ("AverageReturn", "AverageDiscountedReturn", "SuccessRate", "AverageCaptureCount", "AverageStepCount",
+                "AverageMovingCount", "AveragePenaltyCount", "AverageVariable", "AverageVar2", "AveDegree", "Diameter")
+        out = dict(Iteration=itr, NumTrajs=P * N)                                    # :346-347
+        out.update({k: float(v) for k, v in zip(keys, means)})
+        out.update(StdReturn=std, MaxReturn=mx, MinReturn=mn, AveTroughput=trput)
+        return out
+
     # ------------------------------------------------------------------------------------------
     # gradient exchange (SURVEY.md §8e)
     # ------------------------------------------------------------------------------------------
@@ -270,11 +324,9 @@ class CentralizedMAPPO:
             loss_after = float(self._compute_loss(itr, obs, avail, actions, rewards, valids, baselines, dist_adjs,
                                                   channels, advantages, old_ll))
             kl, entropy = self._diagnostics(obs, actions, valids, dist_adjs, channels)
-        mask = self._valid_mask(valids, T)
-        undisc = (rewards * mask).sum(1)
-        avg_return = float(undisc.mean())
-        self.episode_reward_mean.extend(undisc.tolist())
-        self.stats = dict(AverageReturn=avg_return, NumTrajs=P, LossBefore=loss_before, LossAfter=loss_after,
+        perf = self._log_performance(itr, paths, returns, valids)
+        avg_return = perf["AverageReturn"]
+        self.stats = dict(perf, LossBefore=loss_before, LossAfter=loss_after,
                           dLoss=loss_before - loss_after, KLBefore=kl_before, KL=kl, Entropy=entropy,
                           GradNorm=float(np.mean(grad_norm)) if grad_norm else 0.0, EpochTime=epoch_time,
                           TrainOnceTime=time.time() - t_start, MaxPathLength=T,

@@ -8,6 +8,7 @@ The reference's runner scripts import the hot-path classes by these names
     from com_marl.torch.baselines import CommBaseCritic
     from com_marl.torch.algos import CentralizedMAPPO
     from com_marl.sampler import CentralizedMAOnPolicyVectorizedSampler
+    from eval_pp import eval_model                            # / eval_co  (greedy evaluation, §8f-1)
 
 ``install()`` registers module objects under exactly those names (and nothing else of the
 reference: experiment runner, logging, snapshotting stay the reference's own).  A maintainer who
@@ -19,7 +20,7 @@ import types
 
 
 def install(force=False):
-    from . import algos, envs, nets, sampler
+    from . import algos, envs, evaluate, nets, sampler
 
     def mod(name, **attrs):
         if name in sys.modules and not force and not getattr(sys.modules[name], "_commarl_amd", False):
@@ -46,6 +47,8 @@ def install(force=False):
         GraphConvolutionModule=nets.GraphConvolutionModule, GaussianMLPModule=nets.GaussianMLPModule)
     mod("com_marl.torch.algos", CentralizedMAPPO=algos.CentralizedMAPPO)
     mod("com_marl.sampler", CentralizedMAOnPolicyVectorizedSampler=sampler.CentralizedMAOnPolicyVectorizedSampler)
+    mod("eval_pp", eval_model=evaluate.eval_model, VECTORS=evaluate.VECTORS)          # exp_runners/predatorprey/eval_pp.py:9
+    mod("eval_co", eval_model=evaluate.eval_model_co, VECTORS=evaluate.VECTORS)       # exp_runners/coverage/eval_co.py:9
     return sorted(k for k, v in sys.modules.items() if getattr(v, "_commarl_amd", False))
 
 

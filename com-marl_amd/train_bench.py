@@ -52,7 +52,7 @@ def train_loop_measurement(env, policy, cfg, spec, world, rank, dev, seed, epoch
     total = float(tot.item())
     return dict(value=world * env_steps / total, unit="env-steps/s", epochs=epochs,
                 rollout_s_per_epoch=t_roll / epochs, update_s_per_epoch=t_upd / epochs,
-                env_steps_per_epoch_per_gpu=env_steps // epochs, paths_per_epoch=stats.get("NumTrajs"),
+                env_steps_per_epoch_per_gpu=env_steps // epochs, paths_per_epoch=stats.get("NumTrajs", 0) // env.N,
                 schedule="3 minibatches x 10 mini-epochs, Adam lr 3e-4, clip 0.1, grad all-reduce per step" if world > 1
                 else "3 minibatches x 10 mini-epochs, Adam lr 3e-4, clip 0.1",
                 loss_before=stats.get("LossBefore"), loss_after=stats.get("LossAfter"), kl=stats.get("KL"))
