@@ -53,6 +53,15 @@ class CriticWeights(C.Structure):
                                   "dec_b1", "dec_w2t", "dec_b2")]
 
 
+MLP_MAX_LAYERS = 6
+
+
+class MlpWeights(C.Structure):
+    _fields_ = [("in_dim", C.c_int32), ("n_layers", C.c_int32), ("out_dim", C.c_int32 * MLP_MAX_LAYERS),
+                ("tanh_mask", C.c_int32), ("_pad", C.c_int32), ("wt", C.c_void_p * MLP_MAX_LAYERS),
+                ("b", C.c_void_p * MLP_MAX_LAYERS)]
+
+
 # every symbol include/commarl.h declares, with its signature
 _SIGNATURES = {
     "cm_abi_version": (C.c_int, []),
@@ -74,6 +83,10 @@ _SIGNATURES = {
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "cm_critic_forward": (C.c_int, [C.POINTER(CriticWeights), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p]),
+    "cm_mlp_policy_forward": (C.c_int, [C.POINTER(MlpWeights), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                        C.c_void_p, C.c_uint64, C.c_int32, C.c_uint32, C.c_void_p, C.c_int32,
+                                        C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cm_mlp_value_forward": (C.c_int, [C.POINTER(MlpWeights), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cm_masked_agg_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cm_masked_agg_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -112,7 +112,7 @@ class CentralizedMAPPO:
             P = len(paths)
             T = max(len(p['rewards']) for p in paths)
             N = self.policy._n_agents
-            Lh = len(self.policy.gcn_layers)
+            Lh = np.asarray(paths[0]['channels']).shape[-2] // N                    # [T, L*N, N] (sampler.py:191)
 
             def pad(key, val, dtype, tail):
                 out = torch.full((P, T) + tail, val, dtype=dtype)
@@ -132,9 +132,20 @@ class CentralizedMAPPO:
         with torch.cuda.device(dev):
             L.check(L.lib().cm_discount_returns(P, T, L.ptr(rew64.contiguous()), L.ptr(valids), float(self.discount),
                                                 L.ptr(returns), L.current_stream()), "cm_discount_returns")
-        with torch.no_grad():                                                       # :653-655
-            baselines = self.baseline.forward(obs, None, dist_adjs, channels)
+        with torch.no_grad():                                                       # :653-657
+            baselines = self._baseline_forward(obs, dist_adjs, channels)
         return obs, None, actions, rewards, valids, baselines, returns, dist_adjs, channels
+
+    # baseline dispatch (:230-233, :654-657): the GNN critic takes the graph, plain baselines only obs
+    def _baseline_forward(self, obs, dist_adjs, channels):
+        if self.baseline.name in ['base_critic']:
+            return self.baseline.forward(obs, None, dist_adjs, channels)
+        return self.baseline.forward(obs)
+
+    def _baseline_loss(self, obs, returns, dist_adjs, channels):
+        if self.baseline.name in ['base_critic']:
+            return self.baseline.compute_loss(obs, returns, dist_adjs, channels)
+        return self.baseline.compute_loss(obs, returns)
 
     # ------------------------------------------------------------------------------------------
     # loss pieces
@@ -305,11 +316,11 @@ class CentralizedMAPPO:
                 self._baseline_optimizer.zero_grad()
                 self._optimizer.zero_grad()
                 if distributed:
-                    (self.baseline.compute_loss(o, returns[ids], da, ch) * n_crit).backward()
+                    (self._baseline_loss(o, returns[ids], da, ch) * n_crit).backward()
                     loss_sum.backward()
                     self._allreduce_grads(n_valid, n_crit)
                 else:
-                    self.baseline.compute_loss(o, returns[ids], da, ch).backward()
+                    self._baseline_loss(o, returns[ids], da, ch).backward()
                     (loss_sum / n_valid).backward()
                 if self._clip_grad_norm is not None:                                 # policy only (:253-255)
                     torch.nn.utils.clip_grad_norm_(self.policy.parameters(), self._clip_grad_norm)

@@ -41,8 +41,10 @@ def install(force=False):
     mod("envs.coverage_wrapper", CoverageWrapper=envs.CoverageWrapper)
     mod("com_marl")
     mod("com_marl.torch")
-    mod("com_marl.torch.policies", CommCategoricalMLPPolicy=nets.CommCategoricalMLPPolicy)
-    mod("com_marl.torch.baselines", CommBaseCritic=nets.CommBaseCritic)
+    mod("com_marl.torch.policies", CommCategoricalMLPPolicy=nets.CommCategoricalMLPPolicy,
+        DecCategoricalMLPPolicy=nets.DecCategoricalMLPPolicy,                           # runner_pp_obsDP.py:28
+        CentralizedCategoricalMLPPolicy=nets.CentralizedCategoricalMLPPolicy)           # runner_pp_cent.py:28
+    mod("com_marl.torch.baselines", CommBaseCritic=nets.CommBaseCritic, GaussianMLPBaseline=nets.GaussianMLPBaseline)
     mod("com_marl.torch.modules", CommBaseNet=nets.CommBaseNet, AttentionModule=nets.AttentionModule,
         GraphConvolutionModule=nets.GraphConvolutionModule, GaussianMLPModule=nets.GaussianMLPModule)
     mod("com_marl.torch.algos", CentralizedMAPPO=algos.CentralizedMAPPO)

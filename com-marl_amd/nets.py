@@ -236,7 +236,59 @@ def _as_dev(x, device):
     return x.to(device=device, dtype=torch.float32)
 
 
-class CommBaseNet(nn.Module):
+class _WeightPack:
+    """Flat device copy of a net's (transposed) weights for the fused C-ABI kernels; subclasses list the
+    tensors in ``_pack_tensors()``."""
+    _pack_sig, _pack = None, None
+
+    def _pack_tensors(self):
+        raise NotImplementedError
+
+    def _packed(self):
+        """Flat contiguous device copy of the (transposed) weights.  Allocated once; when a parameter
+        changed (optimizer step / load_state_dict) the SAME buffer is rewritten in place, so device
+        pointers - and any hipGraph that captured them - stay valid."""
+        sig = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if sig == self._pack_sig:
+            return self._pack[1]
+        with torch.no_grad():
+            ts = self._pack_tensors()
+            if self._pack is None or self._pack[0].device != next(self.parameters()).device:
+                offs, off = {}, 0
+                for k, v in ts.items():
+                    if v is None:
+                        offs[k] = None
+                        continue
+                    offs[k] = (off, v.numel())
+                    off += (v.numel() + 3) & ~3                 # keep every tensor 16-byte aligned
+                buf = torch.zeros(off, dtype=torch.float32, device=next(self.parameters()).device)
+                base = buf.data_ptr()
+                ptrs = {k: (None if o is None else base + 4 * o[0]) for k, o in offs.items()}
+                self._pack = (buf, ptrs, offs)
+            buf, ptrs, offs = self._pack
+            for k, v in ts.items():
+                if v is not None:
+                    o, n = offs[k]
+                    buf[o:o + n].copy_(v.detach().to(torch.float32).reshape(-1))
+            self._pack_sig = sig
+        return self._pack[1]
+
+    def sync_weights(self):
+        """Refresh the fused kernels' weight pack (call after an optimizer step, outside graphs)."""
+        self._packed()
+
+    def grad_norm(self):
+        return float(np.sqrt(np.sum([p.grad.norm(2).item() ** 2 for p in self.parameters() if p.grad is not None])))
+
+    def reset(self, dones=None):
+        return
+
+    @property
+    def recurrent(self):
+        return False
+
+
+class CommBaseNet(_WeightPack, nn.Module):
     """comm_base_net.py:11-111."""
 
     def __init__(self, env_spec, n_agents, encoder_hidden_sizes=(128,), embedding_dim=64, attention_type="general",
@@ -260,19 +312,8 @@ class CommBaseNet(nn.Module):
         self.gcn_layers = nn.ModuleList([GraphConvolutionModule(embedding_dim, embedding_dim, bias=gcn_bias, id=i)
                                          for i in range(n_gcn_layers)])
         self._enc_hidden = tuple(encoder_hidden_sizes)
-        self._pack_sig, self._pack = None, None
 
     # -- helpers --------------------------------------------------------------------------------
-    def grad_norm(self):
-        return float(np.sqrt(np.sum([p.grad.norm(2).item() ** 2 for p in self.parameters() if p.grad is not None])))
-
-    def reset(self, dones=None):
-        return
-
-    @property
-    def recurrent(self):
-        return False
-
     def _flatten(self, obs_n, dist_adj, channels):
         """Reference reshapes (comm_categorical_mlp_policy.py:56-71): obs [...,N*d] -> [S,N,d],
         dist_adj [...,N*N]|[...,N,N] -> [S,N,N], channels [...,L*N,N]|[...,L,N,N] -> [S,L,N,N]."""
@@ -313,39 +354,10 @@ class CommBaseNet(nn.Module):
     def _head_tensors(self):
         raise NotImplementedError
 
-    def _packed(self):
-        """Flat contiguous device copy of the (transposed) weights.  Allocated once; when a parameter
-        changed (optimizer step / load_state_dict) the SAME buffer is rewritten in place, so device
-        pointers - and any hipGraph that captured them - stay valid."""
-        sig = tuple((p.data_ptr(), p._version) for p in self.parameters())
-        if sig == self._pack_sig:
-            return self._pack[1]
-        with torch.no_grad():
-            ts = self._trunk_tensors()
-            ts.update(self._head_tensors())
-            if self._pack is None or self._pack[0].device != next(self.parameters()).device:
-                offs, off = {}, 0
-                for k, v in ts.items():
-                    if v is None:
-                        offs[k] = None
-                        continue
-                    offs[k] = (off, v.numel())
-                    off += (v.numel() + 3) & ~3                 # keep every tensor 16-byte aligned
-                buf = torch.zeros(off, dtype=torch.float32, device=next(self.parameters()).device)
-                base = buf.data_ptr()
-                ptrs = {k: (None if o is None else base + 4 * o[0]) for k, o in offs.items()}
-                self._pack = (buf, ptrs, offs)
-            buf, ptrs, offs = self._pack
-            for k, v in ts.items():
-                if v is not None:
-                    o, n = offs[k]
-                    buf[o:o + n].copy_(v.detach().to(torch.float32).reshape(-1))
-            self._pack_sig = sig
-        return self._pack[1]
-
-    def sync_weights(self):
-        """Refresh the fused kernels' weight pack (call after an optimizer step, outside graphs)."""
-        self._packed()
+    def _pack_tensors(self):
+        ts = self._trunk_tensors()
+        ts.update(self._head_tensors())
+        return ts
 
 
 # ---------------------------------------------------------------------------------------------
@@ -482,13 +494,13 @@ class GaussianMLPModule(nn.Module):
     def __init__(self, input_dim, output_dim, hidden_sizes=(32, 32), init_std=1.0, min_std=1e-6):
         super().__init__()
         self._init_std = nn.Parameter(torch.Tensor([init_std]).log())
-        self._min_std_param = math.log(min_std)
+        self._min_std_param = None if min_std is None else math.log(min_std)
         self._mean_module = MLPModule(input_dim, output_dim, hidden_sizes)
 
     def forward(self, x):
         mean = self._mean_module(x)
-        std = self._init_std.clamp(min=self._min_std_param).exp()
-        return mean, std
+        ls = self._init_std if self._min_std_param is None else self._init_std.clamp(min=self._min_std_param)
+        return mean, ls.exp()
 
 
 class CommBaseCritic(CommBaseNet):
@@ -559,3 +571,207 @@ class CommBaseCritic(CommBaseNet):
         """Gaussian NLL with the shared learned std; padded steps are included in the mean (:59-89)."""
         values, std = self._values_grad(obs_n, dist_adj, channels)
         return -Normal(values, std.mean()).log_prob(returns).mean()
+
+
+# ---------------------------------------------------------------------------------------------
+# Obs-DP / CENT variants (SURVEY.md §8f-2): no communication, plain row-wise MLPs
+# ---------------------------------------------------------------------------------------------
+class _RowMLPPolicy(_WeightPack):
+    """Shared rollout path of the two non-communicating policies: one fused HIP launch
+    (cm_mlp_policy_forward, csrc/cm_mlp.hip) over the layer chain listed by ``_chain()``."""
+
+    def _chain(self):
+        """-> list of (nn.Linear, tanh?) in forward order."""
+        raise NotImplementedError
+
+    def _pack_tensors(self):
+        t = OrderedDict()
+        for i, (lin, _) in enumerate(self._chain()):
+            t[f"w{i}t"] = lin.weight.t()
+            t[f"b{i}"] = lin.bias
+        return t
+
+    def _mlp_struct(self):
+        chain = self._chain()
+        if len(chain) > L.MLP_MAX_LAYERS:
+            raise L.CommarlError(f"fused MLP forward takes at most {L.MLP_MAX_LAYERS} linear layers")
+        p = self._packed()
+        w = L.MlpWeights()
+        w.in_dim, w.n_layers, w.tanh_mask = chain[0][0].in_features, len(chain), 0
+        for i, (lin, th) in enumerate(chain):
+            w.out_dim[i] = lin.out_features
+            w.wt[i], w.b[i] = p[f"w{i}t"], p[f"b{i}"]
+            w.tanh_mask |= int(bool(th)) << i
+        return w
+
+    def set_rng(self, seed, env_id_offset=0):
+        """Philox stream of the action sampler: counter (env id, policy step, site 7, agent)."""
+        self.seed, self.env_id_offset = int(seed), int(env_id_offset)
+
+    @torch.no_grad()
+    def act_device(self, obs, avail=None, dist_adj=None, channels=None, greedy=False, want_actions=True,
+                   want_probs=True, want_attn=False, out_actions=None, out_probs=None, out_attn=None,
+                   policy_step=None, step_base=None, env_id_offset=None):
+        """obs [S,N*d] (CUDA) -> (actions int32 [S,N], probs [S,N,A], None).  dist_adj / channels are accepted
+        and ignored so the rollout engine drives every policy through one call shape."""
+        dev = obs.device
+        if dev.type != "cuda":
+            raise L.CommarlError("the rollout forward is a HIP kernel: inputs must be CUDA tensors (no CPU fallback)")
+        N, A = self._n_agents, self._action_dim
+        S = obs.numel() // (N * self._dec_obs_dim)
+        obs = obs.contiguous()
+        actions = out_actions if out_actions is not None else (
+            torch.empty(S, N, dtype=torch.int32, device=dev) if want_actions else None)
+        probs = out_probs if out_probs is not None else (
+            torch.empty(S, N, A, dtype=torch.float32, device=dev) if want_probs else None)
+        if policy_step is None:
+            policy_step = self._policy_step
+            self._policy_step += 1
+        rows, groups = (S * N, 1) if self._per_agent_rows else (S, N)
+        w = self._mlp_struct()
+        with torch.cuda.device(dev):
+            L.check(L.lib().cm_mlp_policy_forward(
+                C.byref(w), rows, groups, A, N, L.ptr(obs), L.ptr(None if avail is None else avail.contiguous()),
+                self.seed, self.env_id_offset if env_id_offset is None else int(env_id_offset),
+                policy_step & 0xFFFFFFFF, L.ptr(step_base), int(greedy), L.ptr(actions), L.ptr(probs),
+                L.current_stream()), "cm_mlp_policy_forward")
+        return actions, probs, None
+
+    def get_actions(self, observations, avail_actions, greedy=False):
+        """numpy in / numpy out (dec_categorical_mlp_policy.py:150-176, centralized_...:99-118)."""
+        dev = next(self.parameters()).device
+        obs = _as_dev(observations, dev)
+        S = obs.shape[0]
+        act, probs, _ = self.act_device(obs.reshape(S, -1), _as_dev(avail_actions, dev), greedy=greedy)
+        probs = probs.cpu().numpy()
+        return act.cpu().numpy().astype(np.int64), dict(action_probs=[probs[i] for i in range(S)])
+
+    def forward(self, obs_n, avail_actions_n, get_actions=False):
+        """-> Categorical over [..., N, A] (masked + renormalised)."""
+        dev = next(self.parameters()).device
+        if get_actions:
+            obs_n, avail_actions_n = _as_dev(obs_n, dev), _as_dev(avail_actions_n, dev)
+            _, probs, _ = self.act_device(obs_n.reshape(-1, self._n_agents * self._dec_obs_dim), avail_actions_n,
+                                          want_actions=False)
+            return Categorical(probs=probs.reshape(*obs_n.shape[:-1], self._n_agents, -1).cpu())
+        return Categorical(probs=self._probs(obs_n, avail_actions_n)[0])
+
+    def _masked(self, logits, avail_actions_n):
+        probs = torch.softmax(logits, dim=-1)
+        if avail_actions_n is not None:
+            probs = probs * avail_actions_n.reshape(probs.shape)
+        return probs / probs.sum(dim=-1, keepdim=True)
+
+    def entropy(self, observations, avail_actions):
+        return self.forward(observations, avail_actions).entropy().mean(axis=-1)
+
+    def log_likelihood(self, observations, avail_actions, actions):
+        return self.forward(observations, avail_actions).log_prob(actions).sum(axis=-1)
+
+    @property
+    def vectorized(self):
+        return True
+
+
+class DecCategoricalMLPPolicy(_RowMLPPolicy, MLPModule):
+    """dec_categorical_mlp_policy.py:14-232 (ctor of runner_pp_obsDP.py:52-59).  ``hidden_sizes`` =
+    (encoder hidden, embedding, head hidden); parameters: ``_layers.0`` / ``_output_layers.0`` (head, created
+    first as in the reference) and ``encoder.*``."""
+    _per_agent_rows = True
+
+    def __init__(self, env_spec, n_agents, hidden_sizes=(32, 32), name="DecCategoricalMLPPolicy", device="cpu",
+                 _embedding_dim=64, **unused):
+        self._n_agents = n_agents
+        self._dec_obs_dim = self._obs_dim = int(env_spec.observation_space.flat_dim / n_agents)
+        self._action_dim = env_spec.action_space.n
+        self._embedding_dim = hidden_sizes[1]
+        MLPModule.__init__(self, self._embedding_dim, self._action_dim, (hidden_sizes[-1],))
+        self.encoder = MLPModule(self._obs_dim, self._embedding_dim, (hidden_sizes[0],), output_tanh=True)
+        self.device, self.name, self.step, self.centralized = device, name, 0, True
+        self.seed, self.env_id_offset, self._policy_step = 1, 0, 0
+        self.to(device)
+
+    def _chain(self):
+        e = self.encoder
+        return ([(l.linear, True) for l in e._layers] + [(e._output_layers[0].linear, True)]
+                + [(l.linear, True) for l in self._layers] + [(self._output_layers[0].linear, False)])
+
+    def _probs(self, obs_n, avail_actions_n, dist_adj=None, channels=None):
+        obs = obs_n.reshape(obs_n.shape[:-1] + (self._n_agents, -1))              # :110
+        logits = MLPModule.forward(self, self.encoder(obs))
+        return self._masked(logits, avail_actions_n), None
+
+
+class CentralizedCategoricalMLPPolicy(_RowMLPPolicy, MLPModule):
+    """centralized_categorical_mlp_policy.py:11-144 (ctor of runner_pp_cent.py:51-59): one MLP over the
+    concatenated observation, N x 5 logits, agents' actions independent given the joint observation."""
+    _per_agent_rows = False
+
+    def __init__(self, env_spec, n_agents, hidden_sizes=(32, 32), name="CentralizedCategoricalMLPPolicy", device="cpu",
+                 **unused):
+        self._n_agents = n_agents
+        self._obs_dim = env_spec.observation_space.flat_dim
+        self._dec_obs_dim = self._obs_dim // n_agents
+        self._action_dim = env_spec.action_space.n
+        MLPModule.__init__(self, self._obs_dim, self._action_dim * n_agents, tuple(hidden_sizes))
+        self.device, self.name, self.step, self.centralized = device, name, 0, True
+        self.seed, self.env_id_offset, self._policy_step = 1, 0, 0
+        self.to(device)
+
+    def _chain(self):
+        return [(l.linear, True) for l in self._layers] + [(self._output_layers[0].linear, False)]
+
+    def _probs(self, obs_n, avail_actions_n, dist_adj=None, channels=None):
+        logits = MLPModule.forward(self, obs_n)
+        logits = logits.reshape(logits.shape[:-1] + (self._n_agents, -1))         # :83
+        return self._masked(logits, avail_actions_n), None
+
+
+class GaussianMLPBaseline(_WeightPack, nn.Module):
+    """com_marl/torch/baselines/gaussian_mlp_baseline.py:7-115 (runner_pp_cent.py:61-63): V(s) from the
+    concatenated observation, Gaussian NLL with a learned shared std (no clamp: min_std=None)."""
+
+    def __init__(self, env_spec, hidden_sizes=(32, 32), learn_std=True, init_std=1.0, name="GaussianMLPBaseline",
+                 device="cpu", **unused):
+        super().__init__()
+        self.name = name
+        self.input_dim = env_spec.observation_space.flat_dim
+        self.module = GaussianMLPModule(self.input_dim, 1, hidden_sizes=tuple(hidden_sizes), init_std=init_std,
+                                        min_std=None)
+        if not learn_std:
+            self.module._init_std.requires_grad_(False)
+        self.device = device
+        self.to(device)
+
+    def _chain(self):
+        m = self.module._mean_module
+        return [(l.linear, True) for l in m._layers] + [(m._output_layers[0].linear, False)]
+
+    _pack_tensors = _RowMLPPolicy._pack_tensors
+    _mlp_struct = _RowMLPPolicy._mlp_struct
+
+    @torch.no_grad()
+    def values_device(self, obs):
+        dev = obs.device
+        if dev.type != "cuda":
+            raise L.CommarlError("baseline forward is a HIP kernel: inputs must be CUDA tensors (no CPU fallback)")
+        lead = obs.shape[:-1]
+        rows = obs.numel() // self.input_dim
+        values = torch.empty(rows, dtype=torch.float32, device=dev)
+        w = self._mlp_struct()
+        with torch.cuda.device(dev):
+            L.check(L.lib().cm_mlp_value_forward(C.byref(w), rows, L.ptr(obs.contiguous()), L.ptr(values),
+                                                 L.current_stream()), "cm_mlp_value_forward")
+        return values.reshape(*lead)
+
+    def forward(self, obs):
+        """-> values [P,T] (:100-115).  Under no_grad this is the fused kernel."""
+        if not torch.is_tensor(obs):
+            obs = _as_dev(obs, next(self.parameters()).device)
+        if not torch.is_grad_enabled():
+            return self.values_device(obs)
+        return self.module(obs)[0].flatten(-2)
+
+    def compute_loss(self, obs, returns):
+        mean, std = self.module(obs.reshape(-1, self.input_dim))                  # :93-96
+        return -Normal(mean, std).log_prob(returns.reshape(-1, 1)).mean()

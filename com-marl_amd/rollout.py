@@ -44,7 +44,7 @@ class RolloutEngine:
         """env: envs.GridEnvBatch, or a list of shards of one batch (then every shard runs its own
         policy -> env chain on its own HIP stream: the chains are independent, so kernels of different
         shards overlap and their phases drift apart instead of contending in lockstep).
-        policy: nets.CommCategoricalMLPPolicy on the same device."""
+        policy: nets.CommCategoricalMLPPolicy (or the Obs-DP / CENT policy) on the same device."""
         if isinstance(env, (list, tuple)):
             env = _Parts(list(env)) if len(env) > 1 else env[0]
         self.env, self.policy, self.H = env, policy, int(horizon)
@@ -54,6 +54,7 @@ class RolloutEngine:
         self.id0 = self.parts[0].cfg.env_id_offset
         dev, B, N, M, d, Lh = env.device, env.B, env.N, max(env.M, 1), env.d, env.Lh
         A = policy._action_dim
+        store_attn = store_attn and hasattr(policy, "comm")     # Obs-DP / CENT policies have no attention output
         H = self.H
         f32, i32, u8 = torch.float32, torch.int32, torch.uint8
         z = lambda *shape, dtype=f32: torch.zeros(*shape, dtype=dtype, device=dev)   # noqa: E731

@@ -177,6 +177,34 @@ int cm_policy_forward(const cm_policy_weights *w, int32_t n_samples, const float
 int cm_critic_forward(const cm_critic_weights *w, int32_t n_samples, const float *obs, const float *dist_adj,
                       const float *channels, float *values, void *stream);
 
+/* Plain row-wise MLPs: the non-communicating policies and the Gaussian baseline of the reference's Obs-DP / CENT
+ * runners.  Layer l:  y = x . wt[l] + b[l]  (wt TRANSPOSED [in,out] as above), followed by tanh
+ * when bit l of tanh_mask is set.  First layer at most 128 outputs; any layer at most 1024. */
+#define CM_MLP_MAX_LAYERS 6
+typedef struct cm_mlp_weights {
+    int32_t in_dim, n_layers;
+    int32_t out_dim[CM_MLP_MAX_LAYERS];
+    int32_t tanh_mask, _pad;
+    const float *wt[CM_MLP_MAX_LAYERS];
+    const float *b[CM_MLP_MAX_LAYERS];   /* NULL = no bias */
+} cm_mlp_weights;
+
+/* DecCategoricalMLPPolicy.get_actions (com_marl/torch/policies/dec_categorical_mlp_policy.py:106-176; encoder 2
+ * layers + head 2 layers = one 4-layer chain per AGENT row: rows = S*N, groups = 1) and
+ * CentralizedCategoricalMLPPolicy.get_actions (centralized_categorical_mlp_policy.py:61-118; one chain per ENV row
+ * with N*n_act logits: rows = S, groups = N).  x [rows,in_dim]; the last layer has groups*n_act outputs; per group:
+ * softmax x avail ([rows,groups,n_act] or NULL = ones), renormalise, then argmax (greedy) or inverse-CDF sample on the
+ * Philox stream (counter: env = env_id_offset + flat/agents_per_env, step, site 7, agent = flat % agents_per_env with
+ * flat = row*groups + group - the same stream cm_policy_forward uses).
+ *   out: actions int32 [rows,groups] (or NULL), probs [rows,groups,n_act] (or NULL). */
+int cm_mlp_policy_forward(const cm_mlp_weights *w, int32_t rows, int32_t groups, int32_t n_act, int32_t agents_per_env,
+                          const float *x, const float *avail, uint64_t seed, int32_t env_id_offset,
+                          uint32_t policy_step, const uint32_t *policy_step_base, int32_t greedy, int32_t *actions,
+                          float *probs, void *stream);
+/* GaussianMLPBaseline.forward mean (com_marl/torch/baselines/gaussian_mlp_baseline.py:100-115): the last layer has
+ * one output; values [rows]. */
+int cm_mlp_value_forward(const cm_mlp_weights *w, int32_t rows, const float *x, float *values, void *stream);
+
 /* Adjacency-masked aggregation, one GCN hop, for S samples (comm_base_net.py:101-105 +
  * graph_conv_module.py:63-70):  A = M*R*C; A /= rowsum+1e-12; out = tanh(A.(HW) + b).
  *   attn M [S,N,N]; dist_adj R [S,N,N] or NULL; channel C_l [S,N,N] with element stride

@@ -662,6 +662,43 @@ void cmo_policy_forward(const cmo_policy_weights *w, int S, const float *obs, co
     }
 }
 
+/* Row-wise MLP chain (garage MultiHeadedMLPModule.forward, multi_headed_mlp_module.py:134-149): layer l is
+ * nn.Linear (weight [out,in]) followed by tanh when bit l of tanh_mask is set.  Used for the non-communicating
+ * policies (dec_categorical_mlp_policy.py:106-122: encoder then head per agent row;
+ * centralized_categorical_mlp_policy.py:61-97: one chain per env row) and GaussianMLPBaseline.forward
+ * (gaussian_mlp_baseline.py:100-115).  y [rows, out_dim[n_layers-1]]. */
+void cmo_mlp_forward(int rows, int in_dim, int n_layers, const int32_t *out_dim, int tanh_mask, const float *const *W,
+                     const float *const *b, const float *x, float *y) {
+    int maxw = in_dim;
+    for (int l = 0; l < n_layers; ++l) if (out_dim[l] > maxw) maxw = out_dim[l];
+    float *t0 = (float *)malloc(sizeof(float) * maxw), *t1 = (float *)malloc(sizeof(float) * maxw);
+    for (int r = 0; r < rows; ++r) {
+        memcpy(t0, x + (size_t)r * in_dim, sizeof(float) * in_dim);
+        int in = in_dim;
+        for (int l = 0; l < n_layers; ++l) {
+            linear(1, in, out_dim[l], t0, W[l], b[l], (tanh_mask >> l) & 1, t1);
+            float *t = t0; t0 = t1; t1 = t;
+            in = out_dim[l];
+        }
+        memcpy(y + (size_t)r * in, t0, sizeof(float) * in);
+    }
+    free(t0); free(t1);
+}
+
+/* softmax per group of n_act logits, x avail, renormalise (dec_categorical_mlp_policy.py:113-121,
+ * centralized_categorical_mlp_policy.py:83-97); logits / avail / probs [items, n_act]. */
+void cmo_group_softmax(int items, int n_act, const float *logits, const float *avail, float *probs) {
+    for (int i = 0; i < items; ++i) {
+        const float *lg = logits + (size_t)i * n_act, *av = avail + (size_t)i * n_act;
+        float *p = probs + (size_t)i * n_act;
+        float mx = -INFINITY, sum = 0.0f, msum = 0.0f;
+        for (int a = 0; a < n_act; ++a) if (lg[a] > mx) mx = lg[a];
+        for (int a = 0; a < n_act; ++a) { p[a] = expf(lg[a] - mx); sum += p[a]; }
+        for (int a = 0; a < n_act; ++a) { p[a] = (p[a] / sum) * av[a]; msum += p[a]; }
+        for (int a = 0; a < n_act; ++a) p[a] = p[a] / msum;
+    }
+}
+
 /* inverse-CDF categorical sample; u from Philox(counter = (env, policy_step, 7, agent)).x0 */
 void cmo_sample_actions(int S, int n_agents, int n_act, const float *probs, uint64_t seed, int env_id_offset,
                         uint32_t policy_step, int32_t *actions) {

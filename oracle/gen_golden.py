@@ -444,6 +444,96 @@ def record_policy(ns, env_fix, n_agents, seed=1, take=6):
     return out
 
 
+def record_variants(env_fix, n_agents, seed=21, take=6, with_grads=True):
+    """Obs-DP / CENT policies and the Gaussian baseline at seeded state_dicts on observations
+    of an env fixture: probabilities (all-ones and masked avail), greedy actions, entropy, log-likelihood,
+    values, loss and the gradients of a PPO-shaped scalar through each net."""
+    import contextlib
+    import io
+    ns = ref_loader.load_reference_variants(ref_loader.load_reference())
+    torch.manual_seed(seed)
+    T1 = env_fix['obs'].shape[0]
+    d_total = env_fix['obs'].shape[2]
+    spec = ref_loader.make_env_spec(d_total)
+    nets = dict(dec=ns.DecCategoricalMLPPolicy(spec, n_agents, hidden_sizes=[128, 64, 32]),
+                cent=ns.CentralizedCategoricalMLPPolicy(spec, n_agents=n_agents, hidden_sizes=[128, 64, 32]),
+                gb=ns.GaussianMLPBaseline(env_spec=spec, hidden_sizes=(64, 64, 64)))
+    with torch.no_grad():
+        for net in nets.values():
+            for name, p in net.named_parameters():
+                if name.endswith('bias'):
+                    p.uniform_(-0.1, 0.1)
+    # big matrices are not stored: they are drawn from a seeded numpy stream (xavier-uniform range) that the
+    # tests redraw (tests/test_hip_variants_parity.py::_state_dict) - keeps the fixtures small
+    regen = {}
+    with torch.no_grad():
+        for tag, net in nets.items():
+            for k, (name, p) in enumerate(net.state_dict().items()):
+                if p.numel() > 20000:
+                    lim = float(np.sqrt(6.0 / (p.shape[0] + p.shape[1])))
+                    sd_seed = 1000 * seed + 37 * k + len(tag)
+                    p.copy_(torch.from_numpy(np.random.RandomState(sd_seed).uniform(-lim, lim, tuple(p.shape))
+                                             .astype(np.float32)))
+                    regen[f'{tag}.sd.{name}'] = [sd_seed, lim, list(p.shape)]
+    idx = np.linspace(0, T1 - 1, take).astype(int)
+    obs = env_fix['obs'][idx].reshape(-1, d_total).astype(np.float32)    # [S, N*d]
+    S = obs.shape[0]
+    rng = np.random.RandomState(seed)
+    avail = np.ones((S, n_agents * 5), dtype=np.float32)
+    avail_masked = avail.copy().reshape(S, n_agents, 5)
+    avail_masked[rng.rand(S, n_agents) < 0.3, 1] = 0
+    avail_masked = avail_masked.reshape(S, -1)
+    acts = rng.randint(0, 5, size=(S, n_agents))
+    wts = rng.randn(S).astype(np.float32)
+    out = dict(obs=obs, avail_masked=avail_masked, actions=acts, weights=wts, regen=np.array(json.dumps(regen)))
+    tobs, tav = torch.Tensor(obs), torch.Tensor(avail)
+    for tag in ('dec', 'cent'):
+        pol = nets[tag]
+        with torch.no_grad():
+            for suffix, av in (('', avail), ('_masked', avail_masked)):
+                out[f'{tag}.probs{suffix}'] = pol.forward(obs, av, get_actions=True).probs.numpy()
+            a, info = pol.get_actions(obs, avail_masked, greedy=True)
+            out[f'{tag}.greedy_masked'] = np.asarray(a)
+            out[f'{tag}.entropy'] = pol.entropy(tobs, tav).numpy()
+            out[f'{tag}.loglik'] = pol.log_likelihood(tobs, tav, torch.Tensor(acts)).numpy()
+        scalar = -(pol.log_likelihood(tobs, tav, torch.Tensor(acts)) * torch.Tensor(wts)).mean() \
+            - 0.1 * pol.entropy(tobs, tav).mean()
+        pol.zero_grad()
+        scalar.backward()
+        out[f'{tag}.scalar'] = scalar.detach().numpy()
+        if with_grads:
+            for name, p in pol.named_parameters():
+                if p.numel() <= 20000:
+                    out[f'{tag}.grad.{name}'] = p.grad.clone().numpy()
+                else:                                            # big: keep a strided sample + the norm
+                    out[f'{tag}.gradnorm.{name}'] = p.grad.norm().numpy()
+                    out[f'{tag}.gradrows.{name}'] = p.grad[::16].clone().numpy()
+        for name, p in pol.state_dict().items():
+            if f'{tag}.sd.{name}' not in regen:
+                out[f'{tag}.sd.{name}'] = p.numpy()
+    gb = nets['gb']
+    returns = torch.Tensor(rng.randn(S).astype(np.float32) * 3)
+    with contextlib.redirect_stdout(io.StringIO()):
+        with torch.no_grad():
+            out['gb.values'] = gb.forward(tobs.reshape(1, S, -1)).numpy()[0]
+        loss = gb.compute_loss(tobs.reshape(1, S, -1), returns.reshape(1, S))
+    gb.zero_grad()
+    loss.backward()
+    out['gb.loss'] = loss.detach().numpy()
+    out['gb.returns'] = returns.numpy()
+    if with_grads:
+        for name, p in gb.named_parameters():
+            if p.numel() <= 20000:
+                out[f'gb.grad.{name}'] = p.grad.clone().numpy()
+            else:
+                out[f'gb.gradnorm.{name}'] = p.grad.norm().numpy()
+                out[f'gb.gradrows.{name}'] = p.grad[::16].clone().numpy()
+    for name, p in gb.state_dict().items():
+        if f'gb.sd.{name}' not in regen:
+            out[f'gb.sd.{name}'] = p.numpy()
+    return out
+
+
 def record_ppo_math(ns, seed=5):
     """GAE / returns / per-path normalisation on a ragged 3-path batch."""
     rng = np.random.RandomState(seed)
@@ -489,13 +579,16 @@ def record_adam(ns, seed=9, steps=3):
     return dict(grads=np.stack(grads), params=np.stack(params))
 
 
-def record_ppo_step(seed=11):
+def record_ppo_step(seed=11, kind='comm'):
     """Two optimiser steps of the reference CentralizedMAPPO on paths from the reference sampler
     (PP map10, Tmax 12): process_samples tensors, losses, gradients, clipped grad-norm, parameters
-    after each Adam step."""
-    import copy
-    import types
+    after each Adam step.  kind: 'comm' (Comm-DP, runner_pp_commDP.py:49-74),
+    'obsdp' (runner_pp_obsDP.py:52-72) or 'cent' (runner_pp_cent.py:51-63)."""
+    import contextlib
+    import io
     ns = ref_loader.load_reference_ppo(ref_loader.load_reference())
+    if kind != 'comm':
+        ref_loader.load_reference_variants(ns)
     params = pp_params(10, 1, 0.04, 2, max_env_steps=12)
     random.seed(seed)
     np.random.seed(seed)
@@ -510,8 +603,15 @@ def record_ppo_step(seed=11):
 
         def __getattr__(self, k):
             return getattr(self.__dict__['_e'], k)
-    policy = ns.CommCategoricalMLPPolicy(spec, n_agents=4)
-    critic = ns.CommBaseCritic(spec, n_agents=4)
+    if kind == 'comm':
+        policy = ns.CommCategoricalMLPPolicy(spec, n_agents=4)
+    elif kind == 'obsdp':
+        policy = ns.DecCategoricalMLPPolicy(spec, 4, hidden_sizes=[128, 64, 32], name='dec_categorical_mlp_policy')
+    else:
+        policy = ns.CentralizedCategoricalMLPPolicy(spec, n_agents=4, hidden_sizes=[128, 64, 32], name='centralized')
+    critic = (ns.GaussianMLPBaseline(env_spec=spec, hidden_sizes=(64, 64, 64)) if kind == 'cent'
+              else ns.CommBaseCritic(spec, n_agents=4))
+    gnn_critic = kind != 'cent'
     with torch.no_grad():
         for net in (policy, critic):
             for name, p in net.named_parameters():
@@ -541,7 +641,8 @@ def record_ppo_step(seed=11):
         out['pol0.' + name] = p.clone().numpy()
     for name, p in critic.state_dict().items():
         out['crit0.' + name] = p.clone().numpy()
-    obs, avail, actions, rewards, valids, baselines, returns, dist_adjs, channels = algo.process_samples(0, paths)
+    with contextlib.redirect_stdout(io.StringIO()):          # GaussianMLPBaseline.forward prints shapes
+        obs, avail, actions, rewards, valids, baselines, returns, dist_adjs, channels = algo.process_samples(0, paths)
     P, T = rewards.shape
     out.update(obs=obs.numpy(), actions=actions.numpy().astype(np.int32), rewards=rewards.numpy(),
                valids=valids.numpy(), baselines=baselines.numpy(), returns=returns.numpy(),
@@ -550,7 +651,7 @@ def record_ppo_step(seed=11):
                                    for p in paths]))
     for step in (1, 2):
         loss = algo._compute_loss(0, obs, avail, actions, rewards, valids, baselines, dist_adjs, channels)
-        bl = critic.compute_loss(obs, returns, dist_adjs, channels)
+        bl = critic.compute_loss(obs, returns, dist_adjs, channels) if gnn_critic else critic.compute_loss(obs, returns)
         algo._baseline_optimizer.zero_grad()
         bl.backward()
         algo._optimizer.zero_grad()
@@ -583,11 +684,15 @@ def main():
     def save(name, d):
         if args.only and name != args.only:
             return
+        if callable(d):
+            d = d()
         path = os.path.join(args.out, name + '.npz')
         np.savez_compressed(path, **d)
         print(f'{name:28s} {os.path.getsize(path) / 1024:8.1f} KiB')
 
     fx = {}
+    if args.only and args.only.startswith(('ppo_step', 'variants_', 'ppo_math', 'adam')):
+        return late(save, args)
     # config 1/2: PP map10 sen1 den.04 cap2 (full 200-step horizon, chasing so captures happen)
     fx['pp_map10_cap2'] = record_env(ns, 'pp', pp_params(10, 1, 0.04, 2), B=3, T=230, seed=1, p_random=0.35)
     # short horizon: time-limit dones + auto-resets every 9 steps
@@ -627,9 +732,20 @@ def main():
     save('policy_co_map20', record_policy(ns, fx['co_map20'], 24, take=3))
     save('policy_pp_map30', record_policy(ns, fx['pp_map30_cap4'], 72, take=2))
     save('policy_co_map30_iid', record_policy(ns, fx['co_map30_iid'], 54, take=2))
-    save('ppo_math', record_ppo_math(ns))
-    save('adam', record_adam(ns))
-    save('ppo_step', record_ppo_step())
+    late(save, args, ns)
+
+
+def late(save, args, ns=None):
+    """Fixtures that do not need the env recordings of this run."""
+    ns = ns or ref_loader.load_reference()
+    save('ppo_math', lambda: record_ppo_math(ns))
+    save('adam', lambda: record_adam(ns))
+    save('ppo_step', lambda: record_ppo_step())
+    save('ppo_step_obsdp', lambda: record_ppo_step(seed=12, kind='obsdp'))
+    save('ppo_step_cent', lambda: record_ppo_step(seed=13, kind='cent'))
+    save('variants_pp_map10', lambda: record_variants(np.load(os.path.join(args.out, 'env_pp_map10_cap2.npz')), 4))
+    save('variants_co_map20', lambda: record_variants(np.load(os.path.join(args.out, 'env_co_map20.npz')), 24, take=3))
+    save('variants_pp_map30', lambda: record_variants(np.load(os.path.join(args.out, 'env_pp_map30_cap4.npz')), 72, take=2))
 
 
 if __name__ == '__main__':

@@ -90,6 +90,10 @@ def lib():
         _lib.cmo_discount_cumsum.argtypes = [C.c_int, C.c_void_p, C.c_double, C.c_void_p]
         _lib.cmo_gae.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
         _lib.cmo_philox4x32_10.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.cmo_mlp_forward.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p]
+        _lib.cmo_group_softmax.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.cmo_mlp_forward.restype = _lib.cmo_group_softmax.restype = None
         for f in ("cmo_policy_forward", "cmo_sample_actions", "cmo_critic_forward", "cmo_discount_cumsum",
                   "cmo_gae", "cmo_philox4x32_10", "cmo_ge_transition"):
             getattr(_lib, f).restype = None
@@ -269,6 +273,65 @@ def critic_forward(sd, obs, dist_adj, channels, n_agents, n_threads=1):
     values = np.zeros(S, np.float32)
     lib().cmo_critic_forward(C.byref(w), S, _p(obs), _p(adj), _p(ch), _p(values), n_threads)
     return values
+
+
+def mlp_forward(layers, x):
+    """layers: list of (weight [out,in], bias [out], tanh?) in forward order; x [rows, in] -> [rows, out_last]."""
+    x = _f32(x)
+    rows, in_dim = x.shape
+    ws = [_f32(w) for w, _, _ in layers]
+    bs = [_f32(b) for _, b, _ in layers]
+    out_dim = np.asarray([w.shape[0] for w in ws], np.int32)
+    mask = sum(int(bool(t)) << i for i, (_, _, t) in enumerate(layers))
+    wp = (C.c_void_p * len(ws))(*[_p(w) for w in ws])
+    bp = (C.c_void_p * len(bs))(*[_p(b) for b in bs])
+    y = np.zeros((rows, int(out_dim[-1])), np.float32)
+    lib().cmo_mlp_forward(rows, in_dim, len(ws), _p(out_dim), mask, wp, bp, _p(x), _p(y))
+    return y
+
+
+def _mlp_layers(sd, prefix, n_hidden, out_tanh=False):
+    ls = [(sd[f"{prefix}_layers.{i}.linear.weight"], sd[f"{prefix}_layers.{i}.linear.bias"], True)
+          for i in range(n_hidden)]
+    return ls + [(sd[f"{prefix}_output_layers.0.linear.weight"], sd[f"{prefix}_output_layers.0.linear.bias"], out_tanh)]
+
+
+def _n_hidden(sd, prefix):
+    n = 0
+    while f"{prefix}_layers.{n}.linear.weight" in sd:
+        n += 1
+    return n
+
+
+def group_softmax(logits, avail):
+    lg = _f32(logits)
+    A = lg.shape[-1]
+    av = _f32(np.broadcast_to(np.asarray(avail, np.float32).reshape(-1, A), (lg.size // A, A)))
+    p = np.zeros_like(lg)
+    lib().cmo_group_softmax(lg.size // A, A, _p(lg), _p(av), _p(p))
+    return p
+
+
+def dec_policy_forward(sd, obs, avail, n_agents):
+    """DecCategoricalMLPPolicy.forward (dec_categorical_mlp_policy.py:106-122): obs [S,N*d] -> probs [S,N,A]."""
+    S = obs.shape[0]
+    x = _f32(obs).reshape(S * n_agents, -1)
+    layers = _mlp_layers(sd, "encoder.", _n_hidden(sd, "encoder."), out_tanh=True) + _mlp_layers(sd, "", _n_hidden(sd, ""))
+    lg = mlp_forward(layers, x)
+    return group_softmax(lg, avail).reshape(S, n_agents, -1)
+
+
+def cent_policy_forward(sd, obs, avail, n_agents):
+    """CentralizedCategoricalMLPPolicy.forward (centralized_categorical_mlp_policy.py:61-97)."""
+    S = obs.shape[0]
+    lg = mlp_forward(_mlp_layers(sd, "", _n_hidden(sd, "")), _f32(obs).reshape(S, -1))
+    return group_softmax(lg.reshape(S * n_agents, -1), avail).reshape(S, n_agents, -1)
+
+
+def gaussian_baseline_forward(sd, obs):
+    """GaussianMLPBaseline.forward (gaussian_mlp_baseline.py:100-115): obs [R, N*d] -> values [R]."""
+    pre = "module._mean_module."
+    return mlp_forward(_mlp_layers(sd, pre, _n_hidden(sd, pre)), _f32(obs))[:, 0]
 
 
 def sample_actions(probs, seed, env_id_offset, policy_step):

@@ -253,6 +253,23 @@ def load_reference_ppo(ns=None):
     return ns
 
 
+def load_reference_variants(ns=None):
+    """Additionally import the Obs-DP / CENT policies and the plain Gaussian baseline."""
+    ns = ns or load_reference()
+    if hasattr(ns, "DecCategoricalMLPPolicy"):
+        return ns
+    imp = importlib.import_module
+    _bare_pkg("garage.torch.policies", os.path.join(REF, "garage/torch/policies"))
+    sys.modules["garage.torch.policies"].Policy = imp("garage.torch.policies.base").Policy
+    gm = imp("garage.torch.modules.gaussian_mlp_module")
+    sys.modules["garage.torch.modules"].GaussianMLPModule = gm.GaussianMLPModule
+    ns.DecCategoricalMLPPolicy = imp("com_marl.torch.policies.dec_categorical_mlp_policy").DecCategoricalMLPPolicy
+    ns.CentralizedCategoricalMLPPolicy = imp(
+        "com_marl.torch.policies.centralized_categorical_mlp_policy").CentralizedCategoricalMLPPolicy
+    ns.GaussianMLPBaseline = imp("com_marl.torch.baselines.gaussian_mlp_baseline").GaussianMLPBaseline
+    return ns
+
+
 def make_env_spec(obs_dim_total, n_actions=5):
     """EnvSpec stand-in: the nets read only observation_space.flat_dim / action_space.n."""
     import numpy as np

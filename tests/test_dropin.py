@@ -18,6 +18,8 @@ def test_install_registers_reference_import_names():
         from envs import PredatorPreyWrapper, CoverageWrapper                     # noqa: F401
         from com_marl.torch.policies import CommCategoricalMLPPolicy              # noqa: F401
         from com_marl.torch.baselines import CommBaseCritic                       # noqa: F401
+        from com_marl.torch.policies import DecCategoricalMLPPolicy, CentralizedCategoricalMLPPolicy   # noqa: F401
+        from com_marl.torch.baselines import GaussianMLPBaseline                  # noqa: F401
         from com_marl.torch.algos import CentralizedMAPPO                         # noqa: F401
         from com_marl.sampler import CentralizedMAOnPolicyVectorizedSampler       # noqa: F401
         from eval_pp import eval_model                                            # noqa: F401
@@ -47,6 +49,27 @@ def test_state_dict_names_match_reference():
     # 128 d + 39 621 policy / 128 d + 25 026 critic parameters
     assert sum(p.numel() for p in pol.parameters()) == 128 * 21 + 39621
     assert sum(p.numel() for p in crit.parameters()) == 128 * 21 + 25026
+
+
+def test_variant_state_dict_names_match_reference():
+    """Obs-DP / CENT nets: parameter names and shapes of the reference classes."""
+    import json
+    import os
+    from com_marl_amd import nets
+    from com_marl_amd.envs import EnvSpec, _Box, _Discrete
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "variants_pp_map10.npz"))
+    assert json.loads(str(z["regen"])) == {}                  # small config: every tensor is stored
+    spec = EnvSpec(_Box(np.zeros(84), np.ones(84)), _Discrete(5))
+    made = dict(dec=nets.DecCategoricalMLPPolicy(spec, 4, hidden_sizes=[128, 64, 32]),
+                cent=nets.CentralizedCategoricalMLPPolicy(spec, n_agents=4, hidden_sizes=[128, 64, 32]),
+                gb=nets.GaussianMLPBaseline(env_spec=spec, hidden_sizes=(64, 64, 64)))
+    for tag, net in made.items():
+        pre = tag + ".sd."
+        assert sorted(net.state_dict()) == sorted(k[len(pre):] for k in z.files if k.startswith(pre)), tag
+        for k, v in net.state_dict().items():
+            assert tuple(v.shape) == z[pre + k].shape, (tag, k)
+    assert not hasattr(made["dec"], "comm") and not hasattr(made["cent"], "comm")   # sampler / algo dispatch key
+    assert made["gb"].name != "base_critic"
 
 
 def _args():
