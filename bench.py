@@ -62,6 +62,23 @@ def policy_flops(c, d, L=2):
     return per_agent * N
 
 
+def variant_flops(c, d, kind):
+    """FLOPs per env of the non-communicating policies."""
+    N = c["n_agents"]
+    if kind == "obsdp":      # per agent: d -> 128 -> 64 | 64 -> 32 -> 5 (dec_categorical_mlp_policy.py:78-101)
+        return 2 * (d * 128 + 128 * 64 + 64 * 32 + 32 * 5) * N
+    return 2 * (N * d * 128 + 128 * 64 + 64 * 32 + 32 * 5 * N)      # one chain per env (centralized_...:42-52)
+
+
+def make_policy(kind, spec, n_agents, device):
+    from com_marl_amd import nets
+    if kind == "obsdp":
+        return nets.DecCategoricalMLPPolicy(spec, n_agents, hidden_sizes=[128, 64, 32], device=device)
+    if kind == "cent":
+        return nets.CentralizedCategoricalMLPPolicy(spec, n_agents=n_agents, hidden_sizes=[128, 64, 32], device=device)
+    return nets.CommCategoricalMLPPolicy(spec, n_agents=n_agents, device=device)
+
+
 def host_cores():
     """Threads the CPU leg may use: the affinity mask, capped by the cgroup CPU quota and by the
     16-core share a one-GPU box is given."""
@@ -75,7 +92,7 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("COMMARL_CPU_THREADS", "16"))))
 
 
-def cpu_baseline(c, seed, budget_s=12.0):
+def cpu_baseline(c, seed, budget_s=12.0, kind="commdp"):
     """CPU restatement (oracle/, kind 'port') of the same step - C env step + C policy forward +
     sampler, OpenMP over envs on all host cores - timed on a bounded sample of the workload."""
     import numpy as np
@@ -90,13 +107,18 @@ def cpu_baseline(c, seed, budget_s=12.0):
     from com_marl_amd import envs as E, nets
     spec = E.EnvSpec(E._Box(np.zeros(env.d * env.N), np.ones(env.d * env.N)), E._Discrete(5))
     torch.manual_seed(seed)
-    pol = nets.CommCategoricalMLPPolicy(spec, n_agents=env.N, device="cpu")      # weights only; never run on CPU
+    pol = make_policy(kind, spec, env.N, "cpu")                                   # weights only; never run on CPU
     sd = {k: v.detach().numpy() for k, v in pol.state_dict().items()}
     ones = np.ones((B, env.N, 5), np.float32)
     env.reset()
 
     def one(t):
-        probs, _ = O.policy_forward(sd, env.obs, ones, env.dist_adj, env.channels, env.N, n_threads=cores)
+        if kind == "commdp":
+            probs, _ = O.policy_forward(sd, env.obs, ones, env.dist_adj, env.channels, env.N, n_threads=cores)
+        elif kind == "obsdp":                           # row-MLP restatement is single-threaded
+            probs = O.dec_policy_forward(sd, env.obs.reshape(B, -1), ones, env.N)
+        else:
+            probs = O.cent_policy_forward(sd, env.obs.reshape(B, -1), ones, env.N)
         env.step(O.sample_actions(probs, seed, 0, t), n_threads=cores)
     one(0)
     one(1)
@@ -127,6 +149,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-loop", action="store_true")
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--policy", default="commdp", choices=["commdp", "obsdp", "cent"],
+                    help="Comm-DP GNN policy (the headline) or the reference's Obs-DP / CENT variants (SURVEY.md §8f-2)")
     args = ap.parse_args()
 
     import numpy as np
@@ -165,7 +189,7 @@ def main():
         shards = [env]
     spec = E.EnvSpec(E._Box(np.zeros(env.d * env.N), np.ones(env.d * env.N)), E._Discrete(5))
     torch.manual_seed(args.seed)                       # replicas: identical weights on every rank
-    policy = nets.CommCategoricalMLPPolicy(spec, n_agents=env.N, device=dev)
+    policy = make_policy(args.policy, spec, env.N, dev)
     policy.set_rng(args.seed, env_id_offset=rank * B)
     G = max(1, min(args.chunk, args.steps))
     eng = RolloutEngine(shards, policy, horizon=G)
@@ -230,11 +254,14 @@ def main():
     t_pol = time_kernel(lambda: policy.act_device(
         eng.obs[0].view(B, -1), None, None if eng.dist_adj is None else eng.dist_adj[0],
         None if eng.channels is None else eng.channels[0], out_actions=eng.actions[0], out_probs=eng.probs[0],
-        out_attn=eng.attn[0], policy_step=0, step_base=eng.step_base))
+        out_attn=None if eng.attn is None else eng.attn[0], policy_step=0, step_base=eng.step_base))
     t_env = time_kernel(lambda: env.step_device(eng.actions[0], out=eng._out(0, 0, B)))
     env.check_status()
     b_env, b_pol = algorithmic_bytes(c, env.d, env.adj_const, env.ch_const)
-    flops = policy_flops(c, env.d) * B
+    flops = (policy_flops(c, env.d) if args.policy == "commdp" else variant_flops(c, env.d, args.policy)) * B
+    if args.policy != "commdp":                         # no mask reads, no attention output
+        b_pol = 4 * env.N * env.d + 4 * env.N + 20 * env.N
+    kname = "cm_policy_forward" if args.policy == "commdp" else "cm_mlp_policy_forward"
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath) and B == CONFIGS[args.config]["envs"]:      # PMC figures are per launch of the default batch
@@ -243,13 +270,13 @@ def main():
         except Exception:
             traffic = None
     kernels = {
-        "cm_policy_forward": dict(bound="mfma", achieved=flops / t_pol / 1e12, peak=157.3, unit="TFLOP/s",
+        kname: dict(bound="mfma", achieved=flops / t_pol / 1e12, peak=157.3, unit="TFLOP/s",
                                   frac=flops / t_pol / 1e12 / 157.3, us=t_pol * 1e6,
                                   hbm_GBps=b_pol * B / t_pol / 1e9),
         "cm_env_step": dict(bound="hbm", achieved=b_env * B / t_env / 1e9, peak=8000.0, unit="GB/s",
                             frac=b_env * B / t_env / 1e9 / 8000.0, us=t_env * 1e6),
     }
-    dom = "cm_policy_forward" if t_pol >= t_env else "cm_env_step"
+    dom = kname if t_pol >= t_env else "cm_env_step"
     roofline = dict(kernel=dom, **{k: kernels[dom][k] for k in ("bound", "achieved", "peak", "unit", "frac")},
                     traffic=(traffic or {}).get(dom) if isinstance(traffic, dict) else None,
                     kernels=kernels,
@@ -259,23 +286,27 @@ def main():
 
     out = {
         # BASELINE.json's metric for the headline config; rollout = fused policy forward + sample + env step + auto-reset
-        "metric": ("env-steps/sec (whole node), PredatorPrey M=10 N=4, 4096 envs at 1/2/4/8 GPUs" if args.config == "pp_map10"
-                   else f"env-steps/sec (whole node), {args.config}"),
+        "metric": ("env-steps/sec (whole node), PredatorPrey M=10 N=4, 4096 envs at 1/2/4/8 GPUs"
+                   if (args.config == "pp_map10" and args.policy == "commdp")
+                   else f"env-steps/sec (whole node), {args.config}, {args.policy} policy"),
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": c["label"] + "; one step = fused policy forward + sample + env step with auto-reset, "
+        "config": {"workload": (c["label"] if args.policy == "commdp" else c["label"].replace(
+            "Comm-DP GNN policy", {"obsdp": "Obs-DP policy (per-agent MLP, no communication)",
+                                   "cent": "CENT policy (one MLP over the joint observation)"}[args.policy]))
+                               + "; one step = fused policy forward + sample + env step with auto-reset, "
                                "trajectory written to HBM", "envs_per_gpu": B, "total_envs": B * world, "n_agents": c["n_agents"],
                    "obs_dim": env.d, "graph_chunk": 0 if args.no_graph else G, "streams": ns,
                    "parallelism": f"env-sharded x{world} (no data-path collective in the rollout)"},
         "roofline": roofline,
     }
     if rank == 0 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(c, args.seed)
+        out["cpu_baseline"] = cpu_baseline(c, args.seed, kind=args.policy)
     if not args.no_train_loop:
         try:
             from com_marl_amd.train_bench import train_loop_measurement
-            out["train_loop"] = train_loop_measurement(env, policy, c, spec, world, rank, dev, args.seed)
+            out["train_loop"] = train_loop_measurement(env, policy, c, spec, world, rank, dev, args.seed, kind=args.policy)
         except ImportError:
             out["train_loop"] = None
     if world > 1:

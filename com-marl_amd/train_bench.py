@@ -6,7 +6,7 @@ import time
 import torch
 
 
-def train_loop_measurement(env, policy, cfg, spec, world, rank, dev, seed, epochs=2):
+def train_loop_measurement(env, policy, cfg, spec, world, rank, dev, seed, epochs=2, kind="commdp"):
     from . import nets
     from .algos import CentralizedMAPPO
     from .sampler import CentralizedMAOnPolicyVectorizedSampler
@@ -16,7 +16,10 @@ def train_loop_measurement(env, policy, cfg, spec, world, rank, dev, seed, epoch
             self.batch, self.spec, self.bound_return = batch, spec, 0.0
     mpl = cfg["max_env_steps"]
     torch.manual_seed(seed + 1)
-    critic = nets.CommBaseCritic(spec, n_agents=env.N, device=dev)
+    if kind == "cent":                               # runner_pp_cent.py:61-63
+        critic = nets.GaussianMLPBaseline(env_spec=spec, hidden_sizes=(64, 64, 64), device=dev)
+    else:
+        critic = nets.CommBaseCritic(spec, n_agents=env.N, device=dev)
     algo = CentralizedMAPPO(env_spec=spec, policy=policy, baseline=critic, max_path_length=mpl, discount=0.99,
                             center_adv=True, positive_adv=False, gae_lambda=0.97, policy_ent_coeff=0.1,
                             entropy_method="regularized", clip_grad_norm=7, optimization_n_minibatches=3,
