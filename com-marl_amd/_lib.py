@@ -43,14 +43,14 @@ class PolicyWeights(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("d", "n_agents", "n_hops", "enc_hidden", "emb", "h1", "h2", "h3", "n_act",
                                          "no_residual")] + [
         (n, C.c_void_p) for n in ("enc_w1t", "enc_b1", "enc_w2t", "enc_b2", "attn_wt", "gcn_w", "gcn_b", "hd_w1t",
-                                  "hd_b1", "hd_w2t", "hd_b2", "hd_w3t", "hd_b3", "hd_w4t", "hd_b4")]
+                                  "hd_b1", "hd_w2t", "hd_b2", "hd_w3t", "hd_b3", "hd_w4t", "hd_b4", "mfma_pack")]
 
 
 class CriticWeights(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("d", "n_agents", "n_hops", "enc_hidden", "emb", "dec_hidden",
                                          "no_residual", "_pad")] + [
         (n, C.c_void_p) for n in ("enc_w1t", "enc_b1", "enc_w2t", "enc_b2", "attn_wt", "gcn_w", "gcn_b", "dec_w1t",
-                                  "dec_b1", "dec_w2t", "dec_b2")]
+                                  "dec_b1", "dec_w2t", "dec_b2", "mfma_pack")]
 
 
 MLP_MAX_LAYERS = 6
@@ -83,6 +83,10 @@ _SIGNATURES = {
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "cm_critic_forward": (C.c_int, [C.POINTER(CriticWeights), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p]),
+    "cm_policy_pack_bytes": (C.c_size_t, [C.POINTER(PolicyWeights)]),
+    "cm_policy_pack": (C.c_int, [C.POINTER(PolicyWeights), C.c_void_p, C.c_void_p]),
+    "cm_critic_pack_bytes": (C.c_size_t, [C.POINTER(CriticWeights)]),
+    "cm_critic_pack": (C.c_int, [C.POINTER(CriticWeights), C.c_void_p, C.c_void_p]),
     "cm_mlp_policy_forward": (C.c_int, [C.POINTER(MlpWeights), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                         C.c_void_p, C.c_uint64, C.c_int32, C.c_uint32, C.c_void_p, C.c_int32,
                                         C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -123,7 +127,7 @@ def lib():
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(L, name)      # AttributeError if the .so does not export a declared symbol
             fn.restype, fn.argtypes = res, args
-        if L.cm_abi_version() != 1:
+        if L.cm_abi_version() != 2:
             raise CommarlError("libcommarl_hip.so ABI version mismatch")
         _lib = L
     return _lib

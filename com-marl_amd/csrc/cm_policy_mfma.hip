@@ -16,7 +16,11 @@
 //   * the tiny per-env parts (N x N attention softmax, mask + renorm, A.(HW), 32->5 head,
 //     categorical sample) stay on the VALU against the same LDS tiles.
 // HBM traffic is the algorithmic minimum: obs (+ masks) in, actions / probs / attention out.
+#include <stdio.h>
 #include <stdlib.h>
+
+#include <algorithm>
+#include <vector>
 
 #include "cm_internal.h"
 #include "cm_rng.h"
@@ -41,14 +45,22 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // ~40 of the libm-grade tanhf.  Absolute error <= 2e-7 over the whole range (measured against
 // double tanh in tests/test_hip_policy_parity.py), far inside the 1e-5 parity bar; saturates to
 // +-1 without NaN (exp -> inf gives 1 - 0, exp -> 0 gives 1 - 2).
+#ifndef CM_DIAG
+#define CM_DIAG 0
+#endif
 __device__ __forceinline__ float fast_tanh(float x) {
+#if (CM_DIAG & 2)
+    return x * 0.5f;                                                       // diagnostic: no transcendental work
+#endif
     const float t = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);     // exp(2x) = 2^(2x*log2 e)
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);
 }
 
-struct TrunkW { const float *enc_w1t, *enc_b1, *enc_w2t, *enc_b2, *attn_wt, *gcn_w, *gcn_b; };
-struct PolHead { const float *w1t, *b1, *w2t, *b2, *w3t, *b3, *w4t, *b4; int n_act; };
-struct CritHead { const float *w1t, *b1, *w2t, *b2; };
+// weight pointers: the *_p members point into the operand pack (B fragments), biases and the critic's 64 -> 1 output
+// row stay plain
+struct TrunkW { const float *enc1_p, *enc_b1, *enc2_p, *enc_b2, *attn_p, *gcn_p, *gcn_b; };
+struct PolHead { const float *h1_p, *b1, *h2_p, *b2, *h3_p, *b3, *h4_p, *b4; int n_act; };
+struct CritHead { const float *d1_p, *b1, *w2t, *b2; };
 struct FwdArgs {
     int S, N, d, L, EPB;
     const float *obs, *avail, *adj, *chan;
@@ -58,7 +70,10 @@ struct FwdArgs {
     int32_t *actions;
     float *probs, *attn, *values;
     int stop;          // diagnostic: return after phase `stop` (0 = run everything); COMMARL_FWD_STOP
+    unsigned long long *probe;   // diagnostic (COMMARL_FWD_PROBE): [blocks][NPROBE] shader-clock stamps of thread 0
 };
+constexpr int NPROBE = 16;
+#define CM_PROBE(i) do { if (a.probe && tid == 0) a.probe[(size_t)blockIdx.x * NPROBE + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 
 // One dense layer  out[r][o] = act(sum_k in[r][k] * Wt[k][o] + bias[o]),  r < 16*row_tiles, o < OUT,
 // k < kreal <= KPAD.  load() pulls this wave's B fragments (weights) into registers - it is issued one
@@ -75,19 +90,25 @@ struct Layer {
     // k-slot mapping of the 16x16x4 MFMA: lane group g = lane>>4 supplies k = 16*kq + 4*g + j at step
     // (kq, j).  Each lane's A operands are then 4 CONTIGUOUS words per kq (one ds_read_b128), all of a
     // row tile's reads are issued up front and the MFMAs run back to back behind counted waits.
-    __device__ __forceinline__ void load(const float *__restrict__ Wt, const float *__restrict__ bias, int kreal,
-                                         int wave, int lane, int out_real = OUT) {
+    // The B operands come from the operand pack (pack_layer below): [column tile][kq][lane][4 = j], zero padding
+    // baked in, so a wave fetches one unconditional, fully coalesced 1 KB load per (tile, kq).
+    static constexpr int PACK_FLOATS = CT * (KS / 4) * 64 * 4;
+    __device__ __forceinline__ void load(const float *__restrict__ P, const float *__restrict__ bias, int wave, int lane,
+                                         int out_real = OUT) {
         const int ct0 = CT >= 4 ? wave * NCT : (wave % CT);
-        const int c = lane & 15, g = lane >> 4;
+        const float4 *p4 = reinterpret_cast<const float4 *>(P);
 #pragma unroll
         for (int t = 0; t < NCT; ++t) {
-            const int col = (ct0 + t) * 16 + c;
-            const bool cok = col < out_real;
-            bv[t] = (bias && cok) ? bias[col] : 0.0f;
+            const int col = (ct0 + t) * 16 + (lane & 15);
+            bv[t] = (bias && col < out_real) ? bias[col] : 0.0f;
 #pragma unroll
-            for (int kk = 0; kk < KS; ++kk) {
-                const int k = 16 * (kk >> 2) + 4 * g + (kk & 3);
-                b[t][kk] = (k < kreal && cok) ? Wt[(size_t)k * out_real + col] : 0.0f;
+            for (int kq = 0; kq < KS / 4; ++kq) {
+#if (CM_DIAG & 1)
+                const float4 v = make_float4(0.001f, 0.002f, 0.003f, 0.004f);        // diagnostic: no weight loads
+#else
+                const float4 v = p4[((size_t)(ct0 + t) * (KS / 4) + kq) * 64 + lane];
+#endif
+                b[t][4 * kq + 0] = v.x; b[t][4 * kq + 1] = v.y; b[t][4 * kq + 2] = v.z; b[t][4 * kq + 3] = v.w;
             }
         }
     }
@@ -118,8 +139,13 @@ struct Layer {
                 for (int j = 0; j < 4; ++j) {
 #pragma unroll
                     for (int t = 0; t < NCT; ++t) {
+#if (CM_DIAG & 4)
+                        acc0[t][j] += x0[j] * b[t][4 * kq + j];                      // diagnostic: no matrix-core work
+                        acc1[t][j] += x1[j] * b[t][4 * kq + j];
+#else
                         acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[j], b[t][4 * kq + j], acc0[t], 0, 0, 0);
                         acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[j], b[t][4 * kq + j], acc1[t], 0, 0, 0);
+#endif
                     }
                 }
             }
@@ -254,6 +280,28 @@ __device__ __forceinline__ void agg_mfma(const float *A, int NPA, const float *H
     }
 }
 
+// ---- teams of 4 (the headline config): attention and aggregation without leaving the registers -------------------
+// A 16-row activation tile holds 4 whole envs, so the per-env 4 x 4 score blocks are the DIAGONAL 4 x 4 blocks of the
+// tile's 16 x 16 product Q.E^T: one MFMA chain per tile.  In the D layout lane (c = lane&15, g = lane>>4) holds
+// rows 4g..4g+3 of column c, i.e. for the lanes with (c>>2) == g - whole DPP quads - register r is
+// score[env g][i = r][j = c&3]: softmax over j, the mask product and the row renormalisation are quad reductions,
+// and a 4 x 4 transpose inside the quad turns the result into the A operand of the aggregation MFMA
+// (block-diagonal 16 x 16 A times the tile's 16 rows of H.W).  No LDS round trip, no workgroup barrier.
+template <int CTRL>
+__device__ __forceinline__ float quad_dpp(float v) {
+    const int x = __float_as_int(v);
+    return __int_as_float(__builtin_amdgcn_update_dpp(x, x, CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float quad_max(float v) { v = fmaxf(v, quad_dpp<0xB1>(v)); return fmaxf(v, quad_dpp<0x4E>(v)); }
+__device__ __forceinline__ float quad_sum(float v) { v += quad_dpp<0xB1>(v); return v + quad_dpp<0x4E>(v); }
+// lane q of a quad holds column q of a 4 x 4 block in v[0..3] (v[r] = block[r][q]); returns row q: w[j] = block[q][j]
+__device__ __forceinline__ void quad_transpose(const float v[4], int q, float w[4]) {
+#define CM_QT(JJ, CTRL) { const float t0 = quad_dpp<CTRL>(v[0]), t1 = quad_dpp<CTRL>(v[1]), t2 = quad_dpp<CTRL>(v[2]), \
+                                       t3 = quad_dpp<CTRL>(v[3]); w[JJ] = q == 0 ? t0 : (q == 1 ? t1 : (q == 2 ? t2 : t3)); }
+    CM_QT(0, 0x00) CM_QT(1, 0x55) CM_QT(2, 0xAA) CM_QT(3, 0xFF)
+#undef CM_QT
+}
+
 __host__ __device__ inline size_t lds_floats(int rows_pad, int epb, int N) {
     const int NP = N | 1;
     return (size_t)rows_pad * (SA + 3 * SE) + (size_t)epb * N * NP + rows_pad;
@@ -277,32 +325,167 @@ __global__ __launch_bounds__(TPB) void fwd_mfma_kernel(FwdArgs a, TrunkW tw, Pol
     float *rs = M + (size_t)a.EPB * N * NP;             // [rows_cap]
     float *X = H;                                       // obs staging [rows_cap][SX] over H|T
     constexpr int SX = 2 * SE;                          // 136 words: d <= 128
+    CM_PROBE(0);
 
+    // Global-memory schedule.  Vector-memory results return in issue order, so whatever is needed first is issued
+    // first and every later operand is requested one or two phases before its use: the observation tile, then the
+    // encoder weights; small vectors used deep inside the kernel (GCN biases, the sampler's step counter) ride along
+    // here instead of exposing an L2 round trip in the middle of a phase.
+    constexpr bool EARLY = MAXMK == 0;                  // small teams have the registers to prefetch the head early
+    const bool quad_path = MAXMK == 0 && N == 4 && rows_cap <= 32;      // uniform over the grid
+    constexpr int OBSR = 8;
+    const float *src = a.obs + (size_t)s0 * N * d;
+    const int obs_total = RT * 16 * KPAD;
+    const bool obs_pre = obs_total <= OBSR * TPB;
+    float ox[OBSR];
+    if (obs_pre) {
+#pragma unroll
+        for (int qq = 0; qq < OBSR; ++qq) {
+            const int k = tid + qq * TPB, r = k / KPAD, f = k - r * KPAD;
+            ox[qq] = (k < obs_total && r < rows && f < d) ? src[(size_t)r * d + f] : 0.0f;
+        }
+    }
     Layer<KPAD, EH> l_enc1;
-    l_enc1.load(tw.enc_w1t, tw.enc_b1, d, wave, lane);
+    l_enc1.load(tw.enc1_p, tw.enc_b1, wave, lane);
     Layer<EH, EMB> l_enc2;
-    l_enc2.load(tw.enc_w2t, tw.enc_b2, EH, wave, lane);
+    l_enc2.load(tw.enc2_p, tw.enc_b2, wave, lane);
+    const uint32_t draw_step = a.policy_step + (a.step_base ? *a.step_base : 0u);
+    float gbias[4];                                     // quad path: GCN biases of hops 0/1 for this wave's two column tiles
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        gbias[k] = (quad_path && tw.gcn_b && (k >> 1) < L) ? tw.gcn_b[(size_t)(k >> 1) * EMB + 32 * (wave >> 1) + 16 * (k & 1) + (lane & 15)] : 0.0f;
     // ---- stage observations (coalesced), zero the k-padding and the padded rows ----
-    {
-        const float *src = a.obs + (size_t)s0 * N * d;
-        const int total = RT * 16 * KPAD;
-        for (int k = tid; k < total; k += TPB) {
+    if (obs_pre) {
+#pragma unroll
+        for (int qq = 0; qq < OBSR; ++qq) {
+            const int k = tid + qq * TPB, r = k / KPAD, f = k - r * KPAD;
+            if (k < obs_total) X[(size_t)r * SX + f] = ox[qq];
+        }
+    } else {
+        for (int k = tid; k < obs_total; k += TPB) {
             const int r = k / KPAD, f = k - r * KPAD;
             X[(size_t)r * SX + f] = (r < rows && f < d) ? src[(size_t)r * d + f] : 0.0f;
         }
     }
+    Layer<EMB, EMB> l_sq;                               // 64x64 square layers: attention, then the GCN hops
+    l_sq.load(tw.attn_p, nullptr, wave, lane);
     lds_barrier();
     if (a.stop == 1) return;
+    CM_PROBE(1);
     l_enc1.template run<true>(X, SX, bufA, SA, RT, wave, lane);
-    Layer<EMB, EMB> l_sq;                               // 64x64 square layers: attention, then the GCN hops
-    l_sq.load(tw.attn_wt, nullptr, EMB, wave, lane);
+    Layer<EMB, EMB> l_g;                                // quad path: GCN weights, one hop ahead
+    if (quad_path && L > 0) l_g.load(tw.gcn_p, nullptr, wave, lane);
     lds_barrier();
     if (a.stop == 2) return;
+    CM_PROBE(2);
     l_enc2.template run<true>(bufA, SA, E, SE, RT, wave, lane);
+    Layer<EMB, HEAD == 0 ? H1 : DH> l_x1;               // first head layer (policy 64 -> 128, critic 64 -> 64)
+    if (EARLY) l_x1.load(HEAD == 0 ? ph.h1_p : chd.d1_p, HEAD == 0 ? ph.b1 : chd.b1, wave, lane);
+    Layer<H1, H2> l_h2;
     lds_barrier();
     if (a.stop == 3) return;
+    CM_PROBE(3);
+    if (MAXMK == 0 && quad_path) {
+        const int c = lane & 15, g = lane >> 4, q = lane & 3;
+        const bool diag = (c >> 2) == g;                                 // this lane's quad holds a diagonal block
+        l_sq.template run<false>(E, SE, T, SE, RT, wave, lane);          // Q = E.Wa^T
+        if (L > 0) {
+            l_g.template run<false>(E, SE, bufA, SA, RT, wave, lane);    // H.Wg_0 (hop 0 reads E): same barrier as Q
+            if (L > 1) l_g.load(tw.gcn_p + (size_t)EMB * EMB, nullptr, wave, lane);
+        }
+        if (EARLY && HEAD == 0) l_h2.load(ph.h2_p, ph.b2, wave, lane);
+        lds_barrier();
+        if (a.stop == 4) return;
+        CM_PROBE(4);
+        // Wave w owns row tile tw = w & 1 (4 envs) and the output columns 32*(w>>1) .. +31 of every hop: it computes the
+        // scores of ITS tile (16 MFMAs, shared with the wave of the other column half instead of an LDS round trip and
+        // a barrier), keeps attention / A in registers and aggregates two column tiles per hop.
+        const int tw_ = (RT > 1) ? (wave & 1) : 0, ch = wave >> 1;
+        const int rb = 16 * tw_;                                          // first row of this wave's tile
+        v4f sc = (v4f){ 0.f, 0.f, 0.f, 0.f };
+        {
+            const float4 *q0 = reinterpret_cast<const float4 *>(T + (size_t)(rb + c) * SE + 4 * g);
+            const float4 *e0 = reinterpret_cast<const float4 *>(E + (size_t)(rb + c) * SE + 4 * g);
+            float4 qa[EMB / 16], ea[EMB / 16];
+#pragma unroll
+            for (int kq = 0; kq < EMB / 16; ++kq) { qa[kq] = q0[4 * kq]; ea[kq] = e0[4 * kq]; }
+#pragma unroll
+            for (int kq = 0; kq < EMB / 16; ++kq) {
+                sc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[kq].x, ea[kq].x, sc, 0, 0, 0);
+                sc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[kq].y, ea[kq].y, sc, 0, 0, 0);
+                sc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[kq].z, ea[kq].z, sc, 0, 0, 0);
+                sc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[kq].w, ea[kq].w, sc, 0, 0, 0);
+            }
+        }
+        // softmax over j (the quad), exp / reciprocal on the hardware units (1 ulp: far inside the 1e-5 bar)
+        float m[4];                                                      // m[r] = attention[env 4*tw+g][i = r][j = q]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float ex = __builtin_amdgcn_exp2f((sc[r] - quad_max(sc[r])) * 1.4426950408889634f);
+            m[r] = ex * __builtin_amdgcn_rcpf(quad_sum(ex));
+        }
+        if (a.stop == 42) return;
+        CM_PROBE(5);
+        const int env_l = 4 * tw_ + g;                                    // this quad's env (valid on diag lanes)
+        const bool live = diag && env_l < envs;
+        const size_t env_g = (size_t)s0 + min(env_l, envs - 1);
+        if (a.attn && ch == 0 && live) {                                  // one wave per tile stores it: 64 B per env
+            float *dst = a.attn + env_g * 16 + q;
+            dst[0] = m[0]; dst[4] = m[1]; dst[8] = m[2]; dst[12] = m[3];
+        }
+        if (a.stop == 5) return;
+        for (int l = 0; l < L; ++l) {
+            const float *HW = (l & 1) ? T : bufA;                        // hop l's H.Wg_l (Q in T is dead after the scores)
+            const int hws = (l & 1) ? SE : SA;
+            const bool last = l == L - 1;
+            float v[4], w[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                                // A = M * Range * Chan_l (comm_base_net.py:101)
+                float x = m[r];
+                if (a.adj) x *= a.adj[env_g * 16 + 4 * r + q];
+                if (a.chan) x *= a.chan[(env_g * L + l) * 16 + 4 * r + q];
+                v[r] = x * __builtin_amdgcn_rcpf(quad_sum(x) + 1e-12f);  // :102-103
+            }
+            quad_transpose(v, q, w);
+            v4f acc[2] = { (v4f){ 0.f, 0.f, 0.f, 0.f }, (v4f){ 0.f, 0.f, 0.f, 0.f } };
+            float hb[2][4];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) hb[t][j] = HW[(size_t)(rb + 4 * g + j) * hws + 32 * ch + 16 * t + c];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float aop = diag ? w[j] : 0.0f;
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop, hb[0][j], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop, hb[1][j], acc[1], 0, 0, 0);
+            }
+            if (RT > 1 || (wave & 1) == 0) {                              // single-tile workgroups: odd waves duplicate tile 0
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int col = 32 * ch + 16 * t + c;
+                    const float bv = l < 2 ? (l == 0 ? gbias[t] : gbias[2 + t]) : (tw.gcn_b ? tw.gcn_b[(size_t)l * EMB + col] : 0.0f);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const size_t o = (size_t)(rb + 4 * g + r) * SE + col;
+                        const float hv = fast_tanh(acc[t][r] + bv);      // graph_conv_module.py:65-70
+                        H[o] = (last && !a.no_residual) ? E[o] + hv : hv;        // policy :74-77
+                    }
+                }
+            }
+            lds_barrier();
+            if (a.stop == 61 + l) return;
+            CM_PROBE(6 + 2 * l);
+            if (!last) {
+                l_g.template run<false>(H, SE, (l & 1) ? bufA : T, (l & 1) ? SA : SE, RT, wave, lane);   // H.Wg_{l+1}
+                if (l + 2 < L) l_g.load(tw.gcn_p + (size_t)(l + 2) * EMB * EMB, nullptr, wave, lane);
+                lds_barrier();
+                CM_PROBE(7 + 2 * l);
+            }
+        }
+    } else {
+    if (EARLY && HEAD == 0) l_h2.load(ph.h2_p, ph.b2, wave, lane);
     l_sq.template run<false>(E, SE, T, SE, RT, wave, lane);                                  // Q = E.Wa^T
-    if (L > 0) l_sq.load(tw.gcn_w, nullptr, EMB, wave, lane);
+    if (L > 0) l_sq.load(tw.gcn_p, nullptr, wave, lane);
     lds_barrier();
     if (a.stop == 4) return;
     // ---- attention scores + softmax: N x N per env ----
@@ -385,7 +568,7 @@ __global__ __launch_bounds__(TPB) void fwd_mfma_kernel(FwdArgs a, TrunkW tw, Pol
         }
         l_sq.template run<false>(Hin, SE, T, SE, RT, wave, lane);                              // H.Wg_l
         if (a.stop == 61 + l) return;
-        if (l + 1 < L) l_sq.load(tw.gcn_w + (size_t)(l + 1) * EMB * EMB, nullptr, EMB, wave, lane);
+        if (l + 1 < L) l_sq.load(tw.gcn_p + (size_t)(l + 1) * EMB * EMB, nullptr, wave, lane);
         if (MAXMK > 0 && big) {
             // masked + renormalised rows of A, one wave per row (coalesced mask reads along j), written into the
             // zero-padded [rows][NPA] tile the aggregation MFMA reads with 16-byte loads
@@ -481,32 +664,36 @@ __global__ __launch_bounds__(TPB) void fwd_mfma_kernel(FwdArgs a, TrunkW tw, Pol
         }
         lds_barrier();
     }
+    }   // !quad_path
     if (a.stop == 6) return;
+    CM_PROBE(10);
     // ---- residual ----
     if (L == 0) {                                       // no hops: x = E (the hop epilogue adds the residual otherwise)
         for (int k = tid; k < rows * EMB; k += TPB) { const int r = k >> 6, o = k & 63; H[(size_t)r * SE + o] = E[(size_t)r * SE + o]; }
         lds_barrier();
     }
 
+    if (!EARLY) l_x1.load(HEAD == 0 ? ph.h1_p : chd.d1_p, HEAD == 0 ? ph.b1 : chd.b1, wave, lane);
     if (HEAD == 0) {
-        Layer<EMB, H1> l_h1;
-        l_h1.load(ph.w1t, ph.b1, EMB, wave, lane);
-        Layer<H1, H2> l_h2;
-        l_h2.load(ph.w2t, ph.b2, H1, wave, lane);
-        l_h1.template run<true>(H, SE, bufA, SA, RT, wave, lane);
+        if (!EARLY) l_h2.load(ph.h2_p, ph.b2, wave, lane);
         Layer<H2, H3> l_h3;
-        l_h3.load(ph.w3t, ph.b3, H2, wave, lane);
+        l_h3.load(ph.h3_p, ph.b3, wave, lane);
+        l_x1.template run<true>(H, SE, bufA, SA, RT, wave, lane);
         lds_barrier();
+        CM_PROBE(11);
         l_h2.template run<true>(bufA, SA, T, SE, RT, wave, lane);
         const int A = ph.n_act;
         Layer<H3, 16> l_h4;                              // 32 -> n_act (<= 8) logits, zero-padded to one column tile
-        l_h4.load(ph.w4t, ph.b4, H3, wave, lane, A);
+        l_h4.load(ph.h4_p, ph.b4, wave, lane, A);
         lds_barrier();
+        CM_PROBE(12);
         l_h3.template run<true>(T, SE, E, SE, RT, wave, lane);
         lds_barrier();
+        CM_PROBE(13);
         if (a.stop == 7) return;
         l_h4.template run<false>(E, SE, bufA, SA, RT, wave, lane);
         lds_barrier();
+        CM_PROBE(14);
         for (int r = tid; r < rows; r += TPB) {
             float lg[MAX_ACT], p[MAX_ACT];
             const float *x = bufA + (size_t)r * SA;
@@ -516,15 +703,17 @@ __global__ __launch_bounds__(TPB) void fwd_mfma_kernel(FwdArgs a, TrunkW tw, Pol
 #pragma unroll
             for (int c = 0; c < MAX_ACT; ++c) if (c < A) mx = fmaxf(mx, lg[c]);
 #pragma unroll
-            for (int c = 0; c < MAX_ACT; ++c) if (c < A) { p[c] = expf(lg[c] - mx); sum += p[c]; }
+            for (int c = 0; c < MAX_ACT; ++c) if (c < A) { p[c] = __builtin_amdgcn_exp2f((lg[c] - mx) * 1.4426950408889634f); sum += p[c]; }
             const size_t grow = (size_t)s0 * N + r;
+            const float rsum = __builtin_amdgcn_rcpf(sum);              // hardware exp2 / rcp: 1 ulp, far inside 1e-5
 #pragma unroll
             for (int c = 0; c < MAX_ACT; ++c) if (c < A) {
                 const float av = a.avail ? a.avail[grow * A + c] : 1.0f;
-                p[c] = (p[c] / sum) * av; msum += p[c];
+                p[c] = (p[c] * rsum) * av; msum += p[c];
             }
+            const float rmsum = __builtin_amdgcn_rcpf(msum);
 #pragma unroll
-            for (int c = 0; c < MAX_ACT; ++c) if (c < A) p[c] = p[c] / msum;
+            for (int c = 0; c < MAX_ACT; ++c) if (c < A) p[c] = p[c] * rmsum;
             if (a.probs) {
 #pragma unroll
                 for (int c = 0; c < MAX_ACT; ++c) if (c < A) a.probs[grow * A + c] = p[c];
@@ -538,7 +727,7 @@ __global__ __launch_bounds__(TPB) void fwd_mfma_kernel(FwdArgs a, TrunkW tw, Pol
                 } else {
                     const int e = r / N, i = r - e * N;
                     const u32x4 xr = philox4x32_10((uint32_t)(a.env_id_offset + s0 + e),
-                                                   a.policy_step + (a.step_base ? *a.step_base : 0u), SITE_ACTION,
+                                                   draw_step, SITE_ACTION,
                                                    (uint32_t)i, a.key0, a.key1);
                     const float u = unit_f32(xr.x);
                     float acc = 0.0f;
@@ -550,10 +739,9 @@ __global__ __launch_bounds__(TPB) void fwd_mfma_kernel(FwdArgs a, TrunkW tw, Pol
                 a.actions[grow] = act;
             }
         }
+        CM_PROBE(15);
     } else {
-        Layer<EMB, DH> l_d1;
-        l_d1.load(chd.w1t, chd.b1, EMB, wave, lane);
-        l_d1.template run<true>(H, SE, T, SE, RT, wave, lane);
+        l_x1.template run<true>(H, SE, T, SE, RT, wave, lane);
         lds_barrier();
         for (int r = tid; r < rows; r += TPB) {
             const float *x = T + (size_t)r * SE;
@@ -590,6 +778,36 @@ static int launch(FwdArgs a, const TrunkW &tw, const PolHead &ph, const CritHead
         attr_set = true;
     }
     const int blocks = (a.S + a.EPB - 1) / a.EPB;
+    static const bool want_probe = getenv("COMMARL_FWD_PROBE") != nullptr;
+    if (want_probe) {                                    // diagnostic: per-phase shader clocks, averaged over workgroups
+        unsigned long long *dbuf = nullptr;
+        const size_t nb = (size_t)blocks * NPROBE * sizeof(unsigned long long);
+        CM_HIP(hipMalloc(&dbuf, nb));
+        CM_HIP(hipMemset(dbuf, 0, nb));
+        a.probe = dbuf;
+        for (int rep = 0; rep < 3; ++rep)
+            hipLaunchKernelGGL((fwd_mfma_kernel<HEAD, KPAD, MAXMK>), dim3(blocks), dim3(TPB), lds, (hipStream_t)stream, a, tw, ph, chd);
+        CM_HIP(hipDeviceSynchronize());
+        std::vector<unsigned long long> h((size_t)blocks * NPROBE);
+        CM_HIP(hipMemcpy(h.data(), dbuf, nb, hipMemcpyDeviceToHost));
+        CM_HIP(hipFree(dbuf));
+        double sum[NPROBE] = { 0 }; int cnt[NPROBE] = { 0 };
+        unsigned long long tmin = ~0ull, tmax = 0;
+        for (int b = 0; b < blocks; ++b) {
+            int prev = 0;
+            tmin = std::min(tmin, h[(size_t)b * NPROBE]);
+            for (int i = 1; i < NPROBE; ++i) {
+                const unsigned long long t = h[(size_t)b * NPROBE + i];
+                if (!t) continue;
+                sum[i] += (double)(t - h[(size_t)b * NPROBE + prev]); ++cnt[i]; prev = i; tmax = std::max(tmax, t);
+            }
+        }
+        fprintf(stderr, "[fwd probe] HEAD=%d blocks=%d span=%llu clk; mean clk per phase:", HEAD, blocks, tmax - tmin);
+        for (int i = 1; i < NPROBE; ++i) if (cnt[i]) fprintf(stderr, " p%d=%.0f", i, sum[i] / cnt[i]);
+        fprintf(stderr, "\n");
+        a.probe = nullptr;
+        return CM_OK;
+    }
     hipLaunchKernelGGL((fwd_mfma_kernel<HEAD, KPAD, MAXMK>), dim3(blocks), dim3(TPB), lds, (hipStream_t)stream, a, tw, ph, chd);
     CM_HIP(hipGetLastError());
     return CM_OK;
@@ -597,7 +815,9 @@ static int launch(FwdArgs a, const TrunkW &tw, const PolHead &ph, const CritHead
 
 template <int HEAD>
 static int dispatch(const FwdArgs &a, const TrunkW &tw, const PolHead &ph, const CritHead &chd, void *stream) {
-    const int kpad = (a.d + 15) & ~15;
+    int kpad = (a.d + 15) & ~15;
+    if (kpad == 16) kpad = 32;            // smallest instantiation (obs dims 1..32)
+    if (kpad == 48) kpad = 64;
     if (a.N > 128) return 1;             // N x N MFMA tiles are built for teams of up to 128 agents
     const int nn = a.N * a.N;
     // N x N products on MFMA from N = 32 up (measured: at N = 24 the padded 32 x 32 tiles lose to the VALU form)
@@ -613,13 +833,69 @@ static int dispatch(const FwdArgs &a, const TrunkW &tw, const PolHead &ph, const
     }
 }
 
+// ---- operand pack ---------------------------------------------------------------------------------------------
+// dst[((ct*KQ + kq)*64 + lane)*4 + j] = Wt[k = 16kq + 4(lane>>4) + j][col = 16ct + (lane&15)], zero outside [K, OUT]
+__global__ void pack_layer_kernel(const float *__restrict__ Wt, int K, int OUT, int KQ, int CT, float *__restrict__ dst) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= CT * KQ * 256) return;
+    const int j = idx & 3, lane = (idx >> 2) & 63, blk = idx >> 8, kq = blk % KQ, ct = blk / KQ;
+    const int k = 16 * kq + 4 * (lane >> 4) + j, col = 16 * ct + (lane & 15);
+    dst[idx] = (k < K && col < OUT) ? Wt[(size_t)k * OUT + col] : 0.0f;
+}
+
+static int kpad_of(int d) { const int k = (d + 15) & ~15; return (k == 32 || k == 64 || k == 80) ? k : (k == 16 ? 32 : (k == 48 ? 64 : 0)); }
+
+struct PackLayout { size_t enc1, enc2, attn, gcn, x1, h2, h3, h4, total; };
+static PackLayout pack_layout(int kpad, int L, bool policy) {
+    PackLayout o{};
+    size_t off = 0;
+    o.enc1 = off; off += (size_t)kpad * EH;
+    o.enc2 = off; off += (size_t)EH * EMB;
+    o.attn = off; off += (size_t)EMB * EMB;
+    o.gcn = off; off += (size_t)L * EMB * EMB;
+    o.x1 = off; off += policy ? (size_t)EMB * H1 : (size_t)EMB * DH;
+    if (policy) { o.h2 = off; off += (size_t)H1 * H2; o.h3 = off; off += (size_t)H2 * H3; o.h4 = off; off += (size_t)H3 * 16; }
+    o.total = off;
+    return o;
+}
+
+static int pack_one(const float *Wt, int K, int OUT, int kpad, int out_pad, float *dst, void *stream) {
+    if (!Wt) return set_error(CM_ERR_ARG, "weight pack: null layer weight");
+    const int KQ = kpad / 16, CT = out_pad / 16, total = CT * KQ * 256;
+    hipLaunchKernelGGL(pack_layer_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, Wt, K, OUT, KQ, CT, dst);
+    CM_HIP(hipGetLastError());
+    return CM_OK;
+}
+
+static int pack_trunk(int d, int L, const float *w1t, const float *w2t, const float *wat, const float *gw, int kpad,
+                      const PackLayout &lo, float *pack, void *stream) {
+    if (int rc = pack_one(w1t, d, EH, kpad, EH, pack + lo.enc1, stream)) return rc;
+    if (int rc = pack_one(w2t, EH, EMB, EH, EMB, pack + lo.enc2, stream)) return rc;
+    if (int rc = pack_one(wat, EMB, EMB, EMB, EMB, pack + lo.attn, stream)) return rc;
+    for (int l = 0; l < L; ++l)
+        if (int rc = pack_one(gw ? gw + (size_t)l * EMB * EMB : nullptr, EMB, EMB, EMB, EMB, pack + lo.gcn + (size_t)l * EMB * EMB, stream)) return rc;
+    return CM_OK;
+}
+
 }  // namespace mf
 
-// entry points used by cm_policy.hip's C-ABI functions; return 1 when the obs dim has no MFMA instantiation
+static bool policy_shape_ok(const cm_policy_weights *w) {
+    return w && w->enc_hidden == mf::EH && w->emb == mf::EMB && w->h1 == mf::H1 && w->h2 == mf::H2 && w->h3 == mf::H3 &&
+           w->n_act >= 1 && w->n_act <= mf::MAX_ACT && w->n_agents >= 1 && w->n_agents <= 128 && w->n_hops >= 0 &&
+           mf::kpad_of(w->d) != 0;
+}
+static bool critic_shape_ok(const cm_critic_weights *w) {
+    return w && w->enc_hidden == mf::EH && w->emb == mf::EMB && w->dec_hidden == mf::DH && w->n_agents >= 1 &&
+           w->n_agents <= 128 && w->n_hops >= 0 && mf::kpad_of(w->d) != 0;
+}
+
+// entry points used by cm_policy.hip's C-ABI functions; return 1 when the shape has no MFMA instantiation or the
+// caller supplied no operand pack (the generic VALU kernel then runs)
 int policy_forward_mfma(const cm_policy_weights *w, int32_t S, const float *obs, const float *avail, const float *adj,
                         const float *chan, uint64_t seed, int32_t env_id_offset, uint32_t policy_step,
                         const uint32_t *step_base, int32_t greedy, int32_t *actions, float *probs, float *attn,
                         void *stream) {
+    if (!w->mfma_pack || !policy_shape_ok(w)) return 1;
     mf::FwdArgs a{};
     a.S = S; a.N = w->n_agents; a.d = w->d; a.L = w->n_hops;
     a.obs = obs; a.avail = avail; a.adj = adj; a.chan = chan;
@@ -627,19 +903,57 @@ int policy_forward_mfma(const cm_policy_weights *w, int32_t S, const float *obs,
     a.env_id_offset = env_id_offset; a.greedy = greedy; a.no_residual = w->no_residual;
     a.actions = actions; a.probs = probs; a.attn = attn;
     { const char *e = getenv("COMMARL_FWD_STOP"); a.stop = e ? atoi(e) : 0; }
-    mf::TrunkW tw{ w->enc_w1t, w->enc_b1, w->enc_w2t, w->enc_b2, w->attn_wt, w->gcn_w, w->gcn_b };
-    mf::PolHead ph{ w->hd_w1t, w->hd_b1, w->hd_w2t, w->hd_b2, w->hd_w3t, w->hd_b3, w->hd_w4t, w->hd_b4, w->n_act };
+    const mf::PackLayout lo = mf::pack_layout(mf::kpad_of(w->d), w->n_hops, true);
+    const float *P = w->mfma_pack;
+    mf::TrunkW tw{ P + lo.enc1, w->enc_b1, P + lo.enc2, w->enc_b2, P + lo.attn, P + lo.gcn, w->gcn_b };
+    mf::PolHead ph{ P + lo.x1, w->hd_b1, P + lo.h2, w->hd_b2, P + lo.h3, w->hd_b3, P + lo.h4, w->hd_b4, w->n_act };
     return mf::dispatch<0>(a, tw, ph, mf::CritHead{}, stream);
 }
 
 int critic_forward_mfma(const cm_critic_weights *w, int32_t S, const float *obs, const float *adj, const float *chan,
                         float *values, void *stream) {
+    if (!w->mfma_pack || !critic_shape_ok(w)) return 1;
     mf::FwdArgs a{};
     a.S = S; a.N = w->n_agents; a.d = w->d; a.L = w->n_hops;
     a.obs = obs; a.adj = adj; a.chan = chan; a.values = values; a.no_residual = w->no_residual;
-    mf::TrunkW tw{ w->enc_w1t, w->enc_b1, w->enc_w2t, w->enc_b2, w->attn_wt, w->gcn_w, w->gcn_b };
-    mf::CritHead chd{ w->dec_w1t, w->dec_b1, w->dec_w2t, w->dec_b2 };
+    const mf::PackLayout lo = mf::pack_layout(mf::kpad_of(w->d), w->n_hops, false);
+    const float *P = w->mfma_pack;
+    mf::TrunkW tw{ P + lo.enc1, w->enc_b1, P + lo.enc2, w->enc_b2, P + lo.attn, P + lo.gcn, w->gcn_b };
+    mf::CritHead chd{ P + lo.x1, w->dec_b1, w->dec_w2t, w->dec_b2 };
     return mf::dispatch<1>(a, tw, mf::PolHead{}, chd, stream);
 }
 
 }  // namespace cm
+
+extern "C" size_t cm_policy_pack_bytes(const cm_policy_weights *w) {
+    if (!cm::policy_shape_ok(w)) return 0;
+    return cm::mf::pack_layout(cm::mf::kpad_of(w->d), w->n_hops, true).total * sizeof(float);
+}
+
+extern "C" int cm_policy_pack(const cm_policy_weights *w, float *pack, void *stream) {
+    using namespace cm;
+    if (!w || !pack) return set_error(CM_ERR_ARG, "cm_policy_pack: null argument");
+    if (!policy_shape_ok(w)) return set_error(CM_ERR_ARG, "cm_policy_pack: this shape has no matrix-core instantiation (cm_policy_pack_bytes() == 0)");
+    const int kpad = mf::kpad_of(w->d);
+    const mf::PackLayout lo = mf::pack_layout(kpad, w->n_hops, true);
+    if (int rc = mf::pack_trunk(w->d, w->n_hops, w->enc_w1t, w->enc_w2t, w->attn_wt, w->gcn_w, kpad, lo, pack, stream)) return rc;
+    if (int rc = mf::pack_one(w->hd_w1t, mf::EMB, mf::H1, mf::EMB, mf::H1, pack + lo.x1, stream)) return rc;
+    if (int rc = mf::pack_one(w->hd_w2t, mf::H1, mf::H2, mf::H1, mf::H2, pack + lo.h2, stream)) return rc;
+    if (int rc = mf::pack_one(w->hd_w3t, mf::H2, mf::H3, mf::H2, mf::H3, pack + lo.h3, stream)) return rc;
+    return mf::pack_one(w->hd_w4t, mf::H3, w->n_act, mf::H3, 16, pack + lo.h4, stream);
+}
+
+extern "C" size_t cm_critic_pack_bytes(const cm_critic_weights *w) {
+    if (!cm::critic_shape_ok(w)) return 0;
+    return cm::mf::pack_layout(cm::mf::kpad_of(w->d), w->n_hops, false).total * sizeof(float);
+}
+
+extern "C" int cm_critic_pack(const cm_critic_weights *w, float *pack, void *stream) {
+    using namespace cm;
+    if (!w || !pack) return set_error(CM_ERR_ARG, "cm_critic_pack: null argument");
+    if (!critic_shape_ok(w)) return set_error(CM_ERR_ARG, "cm_critic_pack: this shape has no matrix-core instantiation (cm_critic_pack_bytes() == 0)");
+    const int kpad = mf::kpad_of(w->d);
+    const mf::PackLayout lo = mf::pack_layout(kpad, w->n_hops, false);
+    if (int rc = mf::pack_trunk(w->d, w->n_hops, w->enc_w1t, w->enc_w2t, w->attn_wt, w->gcn_w, kpad, lo, pack, stream)) return rc;
+    return mf::pack_one(w->dec_w1t, mf::EMB, mf::DH, mf::EMB, mf::DH, pack + lo.x1, stream);
+}

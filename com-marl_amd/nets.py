@@ -271,7 +271,11 @@ class _WeightPack:
                     o, n = offs[k]
                     buf[o:o + n].copy_(v.detach().to(torch.float32).reshape(-1))
             self._pack_sig = sig
+            self._after_pack(self._pack[1])
         return self._pack[1]
+
+    def _after_pack(self, ptrs):
+        """Hook: derived device-side layouts (the matrix-core operand pack) are rebuilt here."""
 
     def sync_weights(self):
         """Refresh the fused kernels' weight pack (call after an optimizer step, outside graphs)."""
@@ -359,6 +363,21 @@ class CommBaseNet(_WeightPack, nn.Module):
         ts.update(self._head_tensors())
         return ts
 
+    def _after_pack(self, ptrs):
+        """(Re)build the matrix-core operand pack (cm_policy_pack / cm_critic_pack) in its own persistent buffer:
+        same address for the life of the net, so captured hipGraphs keep reading fresh weights."""
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            return
+        w = self._struct_from(ptrs)
+        size_fn, pack_fn = (getattr(L.lib(), n) for n in self._mfma_fns)
+        if self._mfma is None or self._mfma.device != dev:
+            nbytes = size_fn(C.byref(w))
+            self._mfma = torch.zeros(nbytes // 4, dtype=torch.float32, device=dev) if nbytes else None
+        if self._mfma is not None:
+            with torch.cuda.device(dev):
+                L.check(pack_fn(C.byref(w), L.ptr(self._mfma), L.current_stream()), self._mfma_fns[1])
+
 
 # ---------------------------------------------------------------------------------------------
 # policy
@@ -424,8 +443,7 @@ class CommCategoricalMLPPolicy(CommBaseNet):
         t["hd_b4"] = h._output_layers[0].linear.bias
         return t
 
-    def _weights_struct(self):
-        p = self._packed()
+    def _struct_from(self, p):
         w = L.PolicyWeights()
         w.d, w.n_agents, w.n_hops = self._dec_obs_dim, self._n_agents, len(self.gcn_layers)
         w.enc_hidden, w.emb = self._enc_hidden[0], self._embedding_dim
@@ -435,6 +453,13 @@ class CommCategoricalMLPPolicy(CommBaseNet):
         for k, v in p.items():
             setattr(w, k, v)
         return w
+
+    def _weights_struct(self):
+        w = self._struct_from(self._packed())
+        w.mfma_pack = None if self._mfma is None else self._mfma.data_ptr()
+        return w
+
+    _mfma, _mfma_fns = None, ("cm_policy_pack_bytes", "cm_policy_pack")
 
     def set_rng(self, seed, env_id_offset=0):
         """Philox stream of the action sampler: counter (env id, policy step, site 7, agent)."""
@@ -527,6 +552,17 @@ class CommBaseCritic(CommBaseNet):
         return OrderedDict(dec_w1t=m._layers[0].linear.weight.t(), dec_b1=m._layers[0].linear.bias,
                            dec_w2t=m._output_layers[0].linear.weight.t(), dec_b2=m._output_layers[0].linear.bias)
 
+    _mfma, _mfma_fns = None, ("cm_critic_pack_bytes", "cm_critic_pack")
+
+    def _struct_from(self, p):
+        w = L.CriticWeights()
+        w.d, w.n_agents, w.n_hops = self._dec_obs_dim, self._n_agents, len(self.gcn_layers)
+        w.enc_hidden, w.emb, w.dec_hidden = self._enc_hidden[0], self._embedding_dim, self._dec_hidden[0]
+        w.no_residual = 0 if self.residual else 1
+        for k, v in p.items():
+            setattr(w, k, v)
+        return w
+
     def _values_grad(self, obs_n, dist_adj, channels):
         lead, S, obs, adj, ch = self._flatten(obs_n, dist_adj, channels)
         E, H, _ = self.trunk(obs, adj, ch)
@@ -544,13 +580,8 @@ class CommBaseCritic(CommBaseNet):
         lead = obs.shape[:-1] if obs.shape[-1] == N * self._dec_obs_dim else obs.shape[:-2]
         S = obs.numel() // (N * self._dec_obs_dim)
         values = out if out is not None else torch.empty(S, dtype=torch.float32, device=dev)
-        p = self._packed()
-        w = L.CriticWeights()
-        w.d, w.n_agents, w.n_hops = self._dec_obs_dim, N, len(self.gcn_layers)
-        w.enc_hidden, w.emb, w.dec_hidden = self._enc_hidden[0], self._embedding_dim, self._dec_hidden[0]
-        w.no_residual = 0 if self.residual else 1
-        for k, v in p.items():
-            setattr(w, k, v)
+        w = self._struct_from(self._packed())
+        w.mfma_pack = None if self._mfma is None else self._mfma.data_ptr()
         with torch.cuda.device(dev):
             L.check(L.lib().cm_critic_forward(C.byref(w), S, L.ptr(obs.contiguous()),
                                               L.ptr(None if dist_adj is None else dist_adj.contiguous()),

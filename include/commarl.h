@@ -19,13 +19,14 @@
  */
 #ifndef COMMARL_H
 #define COMMARL_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define CM_ABI_VERSION 1
+#define CM_ABI_VERSION 2
 
 enum { CM_PP = 0, CM_CO = 1 };                                  /* scenario */
 enum { CM_CH_FC = 0, CM_CH_FL = 1, CM_CH_IID = 2, CM_CH_GE = 3 }; /* channel model */
@@ -150,6 +151,7 @@ typedef struct cm_policy_weights {
     const float *hd_w2t, *hd_b2;     /* ..._layers.1.linear.*                             [128,64] */
     const float *hd_w3t, *hd_b3;     /* ..._layers.2.linear.*                             [64,32] */
     const float *hd_w4t, *hd_b4;     /* ..._output_layers.0.linear.*                      [32,5] */
+    const float *mfma_pack;          /* cm_policy_pack() output, or NULL: without it the generic VALU kernel runs */
 } cm_policy_weights;
 
 typedef struct cm_critic_weights {
@@ -158,7 +160,19 @@ typedef struct cm_critic_weights {
     const float *enc_w1t, *enc_b1, *enc_w2t, *enc_b2, *attn_wt, *gcn_w, *gcn_b;
     const float *dec_w1t, *dec_b1;   /* baseline_aggregator._mean_module._layers.0.linear.*        [64,64] */
     const float *dec_w2t, *dec_b2;   /* baseline_aggregator._mean_module._output_layers.0.linear.* [64,1] */
+    const float *mfma_pack;          /* cm_critic_pack() output, or NULL */
 } cm_critic_weights;
+
+/* Matrix-core operand pack.  The MFMA forward kernels read every dense layer's weights as ready-made
+ * v_mfma_f32_16x16x4_f32 B fragments - [column tile][16-deep k block][lane][4] with the zero padding baked in - so a
+ * wave fetches 1 KB per instruction, unconditionally, instead of 4 predicated dword gathers per fragment.
+ * cm_*_pack_bytes: size of the pack for this net, 0 when the shape has no matrix-core instantiation (then leave
+ * mfma_pack NULL).  cm_*_pack: (re)build it on `stream` from the plain [in,out] weights in *w - call after every
+ * weight update; the buffer is caller-owned and may be rewritten in place (captured hipGraphs keep working). */
+size_t cm_policy_pack_bytes(const cm_policy_weights *w);
+int cm_policy_pack(const cm_policy_weights *w, float *pack, void *stream);
+size_t cm_critic_pack_bytes(const cm_critic_weights *w);
+int cm_critic_pack(const cm_critic_weights *w, float *pack, void *stream);
 
 /* CommCategoricalMLPPolicy.get_actions (comm_categorical_mlp_policy.py:98-119) for S env
  * states in one fused launch: encoder -> attention -> L x (mask, renorm, GCN) -> residual ->

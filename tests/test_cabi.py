@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"libcommarl_hip.so does not export {n}"
     assert set(names) == set(_lib.EXPORTED), "ctypes binding and header disagree"
-    assert lib.cm_abi_version() == 1
+    assert lib.cm_abi_version() == 2
     assert isinstance(lib.cm_last_error(), (bytes, type(None)))
 
 
@@ -35,8 +35,9 @@ def test_struct_layouts_match_header_sizes():
     assert C.sizeof(_lib.RngTape) == 5 * 8
     assert C.sizeof(_lib.StepOut) == 10 * 8
     assert C.sizeof(_lib.EnvState) == 9 * 8
-    assert C.sizeof(_lib.PolicyWeights) == 10 * 4 + 15 * 8
-    assert C.sizeof(_lib.CriticWeights) == 8 * 4 + 11 * 8
+    assert C.sizeof(_lib.PolicyWeights) == 10 * 4 + 16 * 8
+    assert C.sizeof(_lib.CriticWeights) == 8 * 4 + 12 * 8
+    assert C.sizeof(_lib.MlpWeights) == 2 * 4 + 6 * 4 + 2 * 4 + 12 * 8
 
 
 def test_argument_errors_without_gpu():
