@@ -28,540 +28,19 @@
 
 #include "cm_internal.h"
 #include "cm_rng.h"
+#include "cm_env_dev.h"
 
 namespace cm {
 
-constexpr int C_EMPTY = 0, C_AGENT = 1, C_PREY = 2, C_WALL = 3;
-constexpr int WAVE = 64;
-
-__device__ __forceinline__ int dr_of(int a) { return a == 0 ? 1 : (a == 2 ? -1 : 0); }   // predator_prey.py:244-253
-__device__ __forceinline__ int dc_of(int a) { return a == 1 ? -1 : (a == 3 ? 1 : 0); }
-__device__ __forceinline__ bool in_grid(int r, int c, int S) { return (unsigned)r < (unsigned)S && (unsigned)c < (unsigned)S; }
-// (cell / count_adj are defined after the LDS accessors)
-// _neighbour_agents / _neighbour_preys count (predator_prey.py:309-351): D,U,R,L, each bounds-checked
-__device__ __forceinline__ void raise(const EnvDev &p, int code) { atomicCAS(p.status, 0, code); }
-
-// Dynamic LDS of the single-wave workgroup.  Everything is addressed as smem + integer offset so that
-// the compiler keeps the accesses in the LDS address space (ds_read/ds_write), never as flat pointers.
-extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-struct Lds {           // byte offsets into smem (kept in registers: always passed by value)
-    int g;             // [S*S] u8 occupancy tile
-    int ar, ac;        // [N] i16
-    int pr, pc;        // [M] i16
-    int act;           // [N] u8
-    int alive;         // [M] u8
-    int pcnt;          // [M] u8 predator count around prey j
-    int pmv;           // [M] u8 chosen prey move | 8 = tape ran out
-    int vis;           // [S] u32
-#ifdef CM_BOUNDS
-    int nS2, nN, nM, nS;
-    int32_t *status;
-#endif
-};
-
-__host__ __device__ inline int lds_take(int &off, int bytes) { const int o = off; off += (bytes + 15) & ~15; return o; }
-__host__ __device__ inline int lds_env_bytes(int S, int N, int M) {
-    int off = 0;
-    lds_take(off, S * S); lds_take(off, 2 * N); lds_take(off, 2 * N); lds_take(off, 2 * M); lds_take(off, 2 * M);
-    lds_take(off, N); lds_take(off, M); lds_take(off, M); lds_take(off, M); lds_take(off, 4 * S);
-    return off;
-}
-__device__ __forceinline__ Lds make_lds(int S, int N, int M, int base, int32_t *status) {
-    int off = base;
-    Lds l;
-    l.g = lds_take(off, S * S); l.ar = lds_take(off, 2 * N); l.ac = lds_take(off, 2 * N); l.pr = lds_take(off, 2 * M);
-    l.pc = lds_take(off, 2 * M); l.act = lds_take(off, N); l.alive = lds_take(off, M); l.pcnt = lds_take(off, M);
-    l.pmv = lds_take(off, M); l.vis = lds_take(off, 4 * S);
-#ifdef CM_BOUNDS
-    l.nS2 = S * S; l.nN = N; l.nM = M; l.nS = S; l.status = status;
-#endif
-    return l;
-}
-
-// -DCM_BOUNDS builds a checked variant: an out-of-range LDS index raises status -100-site instead of
-// silently reading 0 (LDS out-of-range reads are not faults), used to hunt indexing bugs on the GPU.
-#ifdef CM_BOUNDS
-__device__ __forceinline__ int chk_(const Lds &l, int i, int n, int site) {
-    if ((unsigned)i < (unsigned)n) return i;
-    atomicCAS(l.status, 0, -100 - site);
-    return 0;
-}
-#define chk(l, i, n, site) chk_(l, i, (l).n, site)
-#else
-#define chk(l, i, n, site) (i)
-#endif
-__device__ __forceinline__ uint8_t &Gc(const Lds l, int i) { return smem[l.g + chk(l, i, nS2, 1)]; }
-__device__ __forceinline__ int16_t &AR(const Lds l, int i) { return reinterpret_cast<int16_t *>(smem + l.ar)[chk(l, i, nN, 2)]; }
-__device__ __forceinline__ int16_t &AC(const Lds l, int i) { return reinterpret_cast<int16_t *>(smem + l.ac)[chk(l, i, nN, 3)]; }
-__device__ __forceinline__ int16_t &PR(const Lds l, int i) { return reinterpret_cast<int16_t *>(smem + l.pr)[chk(l, i, nM, 4)]; }
-__device__ __forceinline__ int16_t &PC(const Lds l, int i) { return reinterpret_cast<int16_t *>(smem + l.pc)[chk(l, i, nM, 5)]; }
-__device__ __forceinline__ uint8_t &ACT(const Lds l, int i) { return smem[l.act + chk(l, i, nN, 6)]; }
-__device__ __forceinline__ uint8_t &ALV(const Lds l, int i) { return smem[l.alive + chk(l, i, nM, 7)]; }
-__device__ __forceinline__ uint8_t &PCNT(const Lds l, int i) { return smem[l.pcnt + chk(l, i, nM, 8)]; }
-__device__ __forceinline__ uint8_t &PMV(const Lds l, int i) { return smem[l.pmv + chk(l, i, nM, 9)]; }
-__device__ __forceinline__ uint32_t &VIS(const Lds l, int i) { return reinterpret_cast<uint32_t *>(smem + l.vis)[chk(l, i, nS, 10)]; }
-
-// Branch-free probes: the address is clamped into the tile and the result masked by the bounds test, so the
-// four neighbour reads of count_adj are independent LDS loads (one round trip) instead of four dependent
-// short-circuit branches.
-__device__ __forceinline__ int cell(const Lds l, int r, int c, int S) {
-    const int rr = min(max(r, 0), S - 1), cc = min(max(c, 0), S - 1);
-    const int v = (int)Gc(l, rr * S + cc);
-    return in_grid(r, c, S) ? v : -1;
-}
-// _neighbour_agents / _neighbour_preys count (predator_prey.py:309-351): D,U,R,L, each bounds-checked
-__device__ __forceinline__ int count_adj(const Lds l, int r, int c, int S, int kind) {
-    const int a = cell(l, r + 1, c, S), b = cell(l, r - 1, c, S), d = cell(l, r, c + 1, S), e = cell(l, r, c - 1, S);
-    return (a == kind) + (b == kind) + (d == kind) + (e == kind);
-}
-
-struct Rng {
-    uint32_t gid, step, k0, k1;
-    __device__ __forceinline__ u32x4 at(uint32_t site, uint32_t idx) const { return philox4x32_10(gid, step, site, idx, k0, k1); }
-};
-
-// 4 consecutive uniforms of a link stream starting at flat index f0 (<= 2 Philox calls)
-__device__ __forceinline__ void uniform4(const Rng &rng, uint32_t site, uint32_t f0, float u[4]) {
-    const uint32_t q = f0 >> 2, o = f0 & 3;
-    const u32x4 a = rng.at(site, q);
-    if (o == 0) { u[0] = unit_f32(a.x); u[1] = unit_f32(a.y); u[2] = unit_f32(a.z); u[3] = unit_f32(a.w); return; }
-    const u32x4 b = rng.at(site, q + 1);
-    // window of 4 words starting at component o of (a, b), without a dynamically indexed array
-    const uint32_t w0 = o == 1 ? a.y : (o == 2 ? a.z : a.w);
-    const uint32_t w1 = o == 1 ? a.z : (o == 2 ? a.w : b.x);
-    const uint32_t w2 = o == 1 ? a.w : (o == 2 ? b.x : b.y);
-    const uint32_t w3 = o == 1 ? b.x : (o == 2 ? b.y : b.z);
-    u[0] = unit_f32(w0); u[1] = unit_f32(w1); u[2] = unit_f32(w2); u[3] = unit_f32(w3);
-}
-
 // ---------------------------------------------------------------------------------------
-// Sub-wave groups: LPE lanes per env (16 / 32 / 64), G = 64 / LPE envs per wave.  All G envs of a
-// wave run the same program in lockstep; "group-uniform" values are identical within a group.
-// ---------------------------------------------------------------------------------------
-template <int LPE>
-struct Grp {
-    int sub, sl;                 // group index inside the wave, lane inside the group
-    __device__ __forceinline__ unsigned long long mask() const {
-        return LPE == 64 ? ~0ull : (((1ull << (LPE & 63)) - 1ull) << (sub * LPE));
-    }
-    __device__ __forceinline__ bool any(bool pred) const { return (__ballot(pred) & mask()) != 0ull; }
-    __device__ __forceinline__ int count(bool pred) const { return __popcll(__ballot(pred) & mask()); }
-};
-
-// floor(k / d) for 0 <= k < 2^22, d >= 1, with a precomputed float reciprocal (instead of the ~35
-// instruction integer division): the float product is off by at most one, fixed up exactly.
-__device__ __forceinline__ int fdiv(int k, int d, float rcp) {
-    int q = (int)((float)k * rcp);
-    int r = k - q * d;
-    if (r >= d) { ++q; } else if (r < 0) { --q; }
-    return q;
-}
-
-// ---------------------------------------------------------------------------------------
-// reset: rejection-sampled spawn (predator_prey.py:150-171,206-232; coverage.py:172-196,221-246).
-// Every lane of a group evaluates the same candidate, lane 0 of the group commits it; groups that do
-// not reset (need == false) idle through the loop.
-// ---------------------------------------------------------------------------------------
-template <int SCEN, int LPE>
-__device__ __forceinline__ void do_reset(const EnvDev &p, const Lds l, const Rng rng, const cm_rng_tape &tape, int b,
-                                         const Grp<LPE> g, bool need) {
-    const int S = p.S, N = p.N, M = p.M, sl = g.sl;
-    if (need) {
-        for (int k = sl; k < S * S; k += LPE) Gc(l, k) = (SCEN == CM_CO) ? p.base_grid[k] : (uint8_t)C_EMPTY;
-        if (SCEN == CM_CO) for (int r = sl; r < S; r += LPE) VIS(l, r) = 0u;
-    }
-    __syncthreads();
-    const int lo = (SCEN == CM_CO) ? 1 : 0;                              // randint(1, m) vs randint(0, G-1)
-    const int total = N + M;
-    int e = need ? 0 : total, cursor = 0;
-    bool fail = false;
-    while (__any(e < total)) {
-        const bool act = e < total;
-        const bool is_prey = e >= N;
-        int r = 0, c = 0;
-        bool ok = false;
-        if (act) {
-            if (p.rng_mode == CM_RNG_TAPE) {
-                if (cursor >= tape.spawn_cap) { fail = true; }
-                else {
-                    const int32_t *t = tape.spawn + ((size_t)b * tape.spawn_cap + cursor) * 2;
-                    r = t[0]; c = t[1];
-                    if (r < 0) fail = true;
-                }
-            } else {
-                const u32x4 x = rng.at(SITE_SPAWN, (uint32_t)cursor);
-                const uint32_t sp = (uint32_t)((SCEN == CM_CO) ? S - 2 : S);
-                r = lo + (int)__umulhi(x.x, sp);
-                c = lo + (int)__umulhi(x.y, sp);
-            }
-            ++cursor;
-            if (!fail) {
-                ok = in_grid(r, c, S) && Gc(l, r * S + c) == C_EMPTY;            // _is_cell_vacant
-                if (ok && is_prey) ok = count_adj(l, r, c, S, C_AGENT) == 0;      // predator_prey.py:166
-            }
-        }
-        __syncthreads();                                   // all probes done before anybody commits
-        if (ok && sl == 0) {
-            if (!is_prey) { AR(l, e) = (int16_t)r; AC(l, e) = (int16_t)c; Gc(l, r * S + c) = C_AGENT;
-                            if (SCEN == CM_CO) VIS(l, r) |= (1u << c); }          // coverage.py:187
-            else { PR(l, e - N) = (int16_t)r; PC(l, e - N) = (int16_t)c; Gc(l, r * S + c) = C_PREY; }
-        }
-        __syncthreads();
-        if (ok) ++e;
-        if (fail) e = total;
-    }
-    if (fail && sl == 0) raise(p, CM_ERR_TAPE);
-    if (need) for (int j = sl; j < M; j += LPE) ALV(l, j) = 1;
-    __syncthreads();
-}
-
-// ---------------------------------------------------------------------------------------
-// emission: obs + dist_adj + channels + state write-back
-// ---------------------------------------------------------------------------------------
-template <int SCEN, int LPE>
-__device__ __forceinline__ void emit(const EnvDev &p, const Lds l, const Rng rng, const cm_rng_tape &tape,
-                                     const cm_step_out &out, int b, const Grp<LPE> g, int step_count, int slot) {
-    const int S = p.S, N = p.N, M = p.M, R = p.R, W = p.W, d = p.d, WW = W * W, sl = g.sl;
-    const float rcp_d = p.rcp_d, rcp_W = p.rcp_W, rcp_N = p.rcp_N, rcp_WW = p.rcp_WW, rcp_NN = p.rcp_NN;
-    // ---- observations [N*d], lanes stride the flattened row -> coalesced stores ----
-    if (out.obs) {
-        float *o = out.obs + (size_t)b * N * d;
-        const int total = N * d;
-        for (int k = sl; k < total; k += LPE) {
-            const int i = fdiv(k, d, rcp_d), f = k - i * d;
-            const int r0 = AR(l, i), c0 = AC(l, i);
-            float v;
-            if (SCEN == CM_PP) {
-                if (f < 2 * WW) {                                   // get_neighbors (predator_prey.py:173-181)
-                    const int chn = f >= WW, w = f - chn * WW, wr = fdiv(w, W, rcp_W), wc = w - wr * W;
-                    v = (cell(l, r0 - R + wr, c0 - R + wc, S) == (chn ? C_PREY : C_AGENT)) ? 1.0f : 0.0f;
-                } else if (f == 2 * WW) v = p.lut_row[r0];          // row / G          (:195)
-                else if (f == 2 * WW + 1) v = p.lut_col[c0];        // col / (G-1)      (:195)
-                else v = p.lut_step[step_count];                    // step / Tmax      (:196)
-            } else {
-                if (f < 3 * WW) {                                   // get_local_view (coverage.py:448-480)
-                    const int chn = fdiv(f, WW, rcp_WW), w = f - chn * WW, wr = fdiv(w, W, rcp_W), wc = w - wr * W;
-                    const int rr = r0 - R + wr, cc = c0 - R + wc;
-                    const bool in = in_grid(rr, cc, S);
-                    if (chn == 0) v = (!in || Gc(l, rr * S + cc) == C_WALL) ? 1.0f : 0.0f;
-                    else if (chn == 1) v = (in && Gc(l, rr * S + cc) == C_AGENT) ? 1.0f : 0.0f;
-                    else v = (in && ((VIS(l, rr) >> cc) & 1u)) ? 1.0f : 0.0f;
-                } else if (f == 3 * WW) v = p.lut_row[r0];          // round(row/(S-1), 2) (:206)
-                else if (f == 3 * WW + 1) v = p.lut_col[c0];
-                else v = p.lut_step[step_count];
-            }
-            o[k] = v;
-        }
-    }
-    // ---- range adjacency (env_communication.py:218-243): integer form of cdist <= Rcom_th ----
-    if (out.dist_adj && !p.adj_const) {
-        float *a = out.dist_adj + (size_t)b * N * N;
-        for (int k = sl; k < N * N; k += LPE) {
-            const int i = fdiv(k, N, rcp_N), j = k - i * N;
-            const int dr = AR(l, i) - AR(l, j), dc = AC(l, i) - AC(l, j);
-            a[k] = (dr * dr + dc * dc <= p.rc2) ? 1.0f : 0.0f;
-        }
-    }
-    // ---- channel masks ----
-    const int NN = N * N, L = p.L;
-    if (p.channel == CM_CH_IID && out.channels) {                   // get_iid_channel (:200-214)
-        float *ch = out.channels + (size_t)b * L * NN;
-        const int total = L * NN;
-        if (p.rng_mode == CM_RNG_TAPE) {
-            const float *u = tape.iid_u + ((size_t)b * 2 + slot) * total;
-            for (int k = sl; k < total; k += LPE) {
-                const int ij = k - fdiv(k, NN, rcp_NN) * NN, i = fdiv(ij, N, rcp_N), j = ij - i * N;
-                ch[k] = ((u[k] + (i == j ? 1.0f : 0.0f)) >= p.ploss) ? 1.0f : 0.0f;
-            }
-        } else {
-            const uint32_t site = slot ? SITE_IID_RESET : SITE_IID_STEP;
-            for (int q = sl; q * 4 < total; q += LPE) {
-                const u32x4 x = rng.at(site, (uint32_t)q);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int k = q * 4 + e;
-                    if (k < total) {
-                        const int ij = k - fdiv(k, NN, rcp_NN) * NN, i = fdiv(ij, N, rcp_N), j = ij - i * N;
-                        ch[k] = ((unit_f32(pick(x, e)) + (i == j ? 1.0f : 0.0f)) >= p.ploss) ? 1.0f : 0.0f;
-                    }
-                }
-            }
-        }
-    } else if (p.channel == CM_CH_GE) {                              // env_communication.py:106-157, GE model :121-150
-        float *ch = out.channels ? out.channels + (size_t)b * L * NN : nullptr;
-        uint8_t *gs = p.ge_state + (size_t)b * NN;
-        const uint32_t site = slot ? SITE_GE_RESET : SITE_GE_STEP;
-        const int l0 = slot ? 1 : 0;                                 // reset: hop 0 = all good, then L-1 transitions
-        for (int k0 = sl * 4; k0 < NN; k0 += LPE * 4) {
-            uint8_t s[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) s[e] = (k0 + e < NN) ? (slot ? (uint8_t)1 : gs[k0 + e]) : (uint8_t)0;
-            if (slot && ch)
-                for (int e = 0; e < 4; ++e) if (k0 + e < NN) ch[k0 + e] = 1.0f;
-            for (int hop = l0; hop < L; ++hop) {
-                float ugb[4], ubg[4];
-                if (p.rng_mode == CM_RNG_TAPE) {
-                    const float *u = tape.ge_u + (((size_t)b * 2 + slot) * L + hop) * 2 * NN;
-                    for (int e = 0; e < 4; ++e) { const int k = k0 + e < NN ? k0 + e : NN - 1; ugb[e] = u[k]; ubg[e] = u[NN + k]; }
-                } else {
-                    uniform4(rng, site, (uint32_t)((hop * 2 + 0) * NN + k0), ugb);
-                    uniform4(rng, site, (uint32_t)((hop * 2 + 1) * NN + k0), ubg);
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int k = k0 + e;
-                    if (k >= NN) continue;
-                    const int i = fdiv(k, N, rcp_N), j = k - i * N;
-                    const float eye = (i == j) ? 1.0f : 0.0f;
-                    const bool e_gb = (ugb[e] + eye) < p.pgb, e_bg = (ubg[e] + eye) < p.pbg;
-                    const bool g_next = s[e] && !(s[e] && e_gb), b_next = (!s[e]) && e_bg;
-                    s[e] = (uint8_t)(g_next || b_next);
-                    if (ch) ch[(size_t)hop * NN + k] = (float)s[e];
-                }
-            }
-            for (int e = 0; e < 4; ++e) if (k0 + e < NN) gs[k0 + e] = s[e];
-        }
-    }
-    // ---- state write-back ----
-    for (int i = sl; i < N; i += LPE) p.agent_pos[(size_t)b * N + i] = make_int2(AR(l, i), AC(l, i));
-    if (SCEN == CM_PP) {
-        for (int j = sl; j < M; j += LPE) {
-            p.prey_pos[(size_t)b * M + j] = make_int2(PR(l, j), PC(l, j));
-            p.alive[(size_t)b * M + j] = ALV(l, j);
-        }
-    } else {
-        for (int r = sl; r < S; r += LPE) p.visited[(size_t)b * S + r] = VIS(l, r);
-    }
-}
-
-// ---------------------------------------------------------------------------------------
-// the step kernel
+// the step kernel: a single-wave workgroup steps G = 64 / LPE envs
 // ---------------------------------------------------------------------------------------
 template <int SCEN, int LPE>
 __global__ __launch_bounds__(WAVE) void env_kernel(EnvDev p, const int32_t *__restrict__ actions, cm_rng_tape tape,
                                                   cm_step_out out, int reset_only) {
     constexpr int G = WAVE / LPE;
-    Grp<LPE> g;
-    g.sub = threadIdx.x / LPE; g.sl = threadIdx.x % LPE;
-    const int sl = g.sl;
-    const int b_raw = blockIdx.x * G + g.sub;
-    const bool valid = b_raw < p.B;
-    const int b = valid ? b_raw : p.B - 1;            // idle groups shadow the last env and never commit
-    const Lds l = make_lds(p.S, p.N, p.M, p.lds_env * g.sub, p.status);
-    const int S = p.S, N = p.N, M = p.M;
-    Rng rng{ (uint32_t)(p.env_id_offset + b), p.rng_step[b], p.key0, p.key1 };
-    cm_step_out o = out;
-    if (!valid) { o.obs = nullptr; o.dist_adj = nullptr; o.channels = nullptr; }
-
-    if (reset_only) {
-        do_reset<SCEN, LPE>(p, l, rng, tape, b, g, true);
-        if (!valid) return;
-        if (sl == 0) { p.step_count[b] = 0; if (SCEN == CM_CO) p.total_capture[b] = 0; p.rng_step[b] = rng.step + 1; }
-        emit<SCEN, LPE>(p, l, rng, tape, o, b, g, 0, 1);
-        return;
-    }
-
-    // ---- load SoA state, rebuild the occupancy tile in LDS ----
-    bool bad_action = false;
-    for (int i = sl; i < N; i += LPE) {
-        const int2 q = p.agent_pos[(size_t)b * N + i];
-        AR(l, i) = (int16_t)q.x; AC(l, i) = (int16_t)q.y;
-        const int a = actions[(size_t)b * N + i];
-        const bool bad = (unsigned)a > 4u;
-        bad_action |= bad;
-        ACT(l, i) = (uint8_t)(bad ? 4 : a);
-    }
-    if (SCEN == CM_PP)
-        for (int j = sl; j < M; j += LPE) {
-            const int2 q = p.prey_pos[(size_t)b * M + j];
-            PR(l, j) = (int16_t)q.x; PC(l, j) = (int16_t)q.y;
-            ALV(l, j) = p.alive[(size_t)b * M + j];
-        }
-    for (int k = sl; k < S * S; k += LPE) Gc(l, k) = (SCEN == CM_CO) ? p.base_grid[k] : (uint8_t)C_EMPTY;
-    if (SCEN == CM_CO) for (int r = sl; r < S; r += LPE) VIS(l, r) = p.visited[(size_t)b * S + r];
-    // the reference raises on a bad action (predator_prey.py:255): flag it; the env is left untouched
-    const bool env_bad = g.any(bad_action);
-    if (env_bad && sl == 0 && valid) raise(p, CM_ERR_ACTION);
-    const bool commit = valid && !env_bad;
-    __syncthreads();
-    if (p.stop == 1) return;
-    for (int i = sl; i < N; i += LPE) Gc(l, AR(l, i) * S + AC(l, i)) = C_AGENT;
-    if (SCEN == CM_PP)
-        for (int j = sl; j < M; j += LPE) if (ALV(l, j)) Gc(l, PR(l, j) * S + PC(l, j)) = C_PREY;
-    __syncthreads();
-
-    if (p.stop == 2) return;
-    int step_count = p.step_count[b] + 1;
-    int succ = p.success[b];
-    int done = 0;
-    double reward;
-    int det0 = 0, det1 = 0, det2 = 0, det3 = 0, det4 = 0, det5 = 0;
-
-    if (SCEN == CM_PP) {
-        // ---- agents move in index order (predator_prey.py:497-500, :240-261): group-uniform loop ----
-        int moving = 0;
-        for (int i = 0; i < N; ++i) {
-            const int a = ACT(l, i);
-            bool mv = false;
-            int r = 0, c = 0, nr = 0, nc = 0;
-            if (a != 4) {
-                ++moving;
-                r = AR(l, i); c = AC(l, i); nr = r + dr_of(a); nc = c + dc_of(a);
-                mv = in_grid(nr, nc, S) && Gc(l, nr * S + nc) == C_EMPTY;
-            }
-            __syncthreads();
-            if (mv && sl == 0) { Gc(l, r * S + c) = C_EMPTY; Gc(l, nr * S + nc) = C_AGENT; AR(l, i) = (int16_t)nr; AC(l, i) = (int16_t)nc; }
-            __syncthreads();
-        }
-        if (p.stop == 3) return;
-        // ---- per-prey work that only depends on the (now static) agent layer: one lane per prey ----
-        for (int j = sl; j < M; j += LPE) {
-            int cnt = 0, mv = 4;
-            if (ALV(l, j)) {
-                const int r = PR(l, j), c = PC(l, j);
-                cnt = count_adj(l, r, c, S, C_AGENT);
-                // prey_random_move (:396-407): first of <=5 draws whose target has no predator neighbour
-                const bool captured_now = (p.load == 2) && cnt >= 1 && p.load <= cnt;
-                if (!captured_now) {
-                    bool found = false;
-                    u32x4 x = { 0, 0, 0, 0 };
-                    for (int t = 0; t < 5 && !found; ++t) {
-                        int m;
-                        if (p.rng_mode == CM_RNG_TAPE) {
-                            m = tape.prey[((size_t)b * M + j) * 5 + t];
-                            if (m > 4) { mv = 4 | 8; break; }     // recorded tape ended: only legal if prey gets captured
-                        } else {
-                            if ((t & 3) == 0) x = rng.at(SITE_PREY, (uint32_t)(2 * j + (t >> 2)));
-                            m = prey_move_from_u32(pick(x, t & 3));
-                        }
-                        if (count_adj(l, r + dr_of(m), c + dc_of(m), S, C_AGENT) == 0) { mv = m; found = true; }
-                    }
-                }
-            }
-            PCNT(l, j) = (uint8_t)cnt; PMV(l, j) = (uint8_t)mv;
-        }
-        // prey_watching (:419-423): agents 4-adjacent to a live prey (prey layer still at start-of-phase positions)
-        int wsum = 0;
-        for (int i0 = 0; i0 < N; i0 += LPE) {
-            const int i = i0 + sl;
-            const bool w = i < N && count_adj(l, AR(l, i), AC(l, i), S, C_PREY) > 0;
-            wsum += g.count(w);
-        }
-        __syncthreads();
-        if (p.stop == 4) return;
-        // ---- captures + prey moves in index order (:416-432 / :460-478, :276-301): group-uniform loop ----
-        int capture = 0, penalty = 0;
-        bool tape_short = false;
-        for (int j = 0; j < M; ++j) {
-            const bool alive = ALV(l, j) != 0;
-            bool captured = false, moved = false;
-            int r = 0, c = 0, nr = 0, nc = 0;
-            if (alive) {
-                r = PR(l, j); c = PC(l, j);
-                const int cnt = PCNT(l, j), mvb = PMV(l, j);
-                if (cnt >= 1) {
-                    int need = p.load;
-                    if (p.load != 2) {                                       // reward_individual :467-470
-                        const bool on_r = (r == 0 || r == S - 1), on_c = (c == 0 || c == S - 1);
-                        const int adj = (on_r && on_c) ? 2 : ((on_r || on_c) ? 3 : p.load);   // __create_edges :123-144
-                        const int avail = adj - count_adj(l, r, c, S, C_PREY);
-                        need = p.load < avail ? p.load : avail;
-                    }
-                    if (need <= cnt) { captured = true; ++capture; } else ++penalty;
-                }
-                if (!captured) {
-                    if (mvb & 8) tape_short = true;
-                    const int mv = mvb & 7;
-                    if (mv != 4) {
-                        nr = r + dr_of(mv); nc = c + dc_of(mv);
-                        moved = in_grid(nr, nc, S) && Gc(l, nr * S + nc) == C_EMPTY;
-                    }
-                }
-            }
-            __syncthreads();
-            if (sl == 0) {
-                if (captured) { ALV(l, j) = 0; Gc(l, r * S + c) = C_EMPTY; }      // :301
-                else if (moved) { Gc(l, r * S + c) = C_EMPTY; Gc(l, nr * S + nc) = C_PREY; PR(l, j) = (int16_t)nr; PC(l, j) = (int16_t)nc; }
-            }
-            __syncthreads();
-        }
-        if (p.stop == 5) return;
-        if (tape_short && sl == 0 && commit) raise(p, CM_ERR_TAPE_PREY);
-        // reward in f64 exactly as the Python expression evaluates (:434 / :480); no FMA contraction (build flag)
-        // (step + cap*c) + (mc*m)/N [+ pen*p]: the two count-indexed terms come from host tables built with the
-        // same f64 operations (no f64 division on the device)
-        reward = p.rew_lut[capture] + p.rew_lut[(M + 1) + moving];
-        if (p.load == 2) reward = reward + p.penalty * (double)penalty;
-        det0 = capture; det1 = moving; det2 = penalty; det4 = wsum;
-        bool any_alive = false;
-        for (int j0 = 0; j0 < M; j0 += LPE) any_alive |= g.any(j0 + sl < M && ALV(l, j0 + sl));
-        if (o.prey_alive && commit) for (int j = sl; j < M; j += LPE) o.prey_alive[(size_t)b * M + j] = ALV(l, j);
-        done = (step_count >= p.max_steps) || !any_alive;               // :511-517
-        if (done) succ = any_alive ? 0 : 1;
-    } else {
-        // ---- Coverage.step (:319-378): sequential agents against tile + visited bitmap ----
-        int cap = 0, mov = 0, pen = 0, lazy = 0, rev = 0;
-        for (int i = 0; i < N; ++i) {
-            const int a = ACT(l, i);
-            bool mv = false, seen = false;
-            int r = 0, c = 0, nr = 0, nc = 0;
-            if (a == 4) ++lazy;
-            else {
-                ++mov;
-                r = AR(l, i); c = AC(l, i); nr = r + dr_of(a); nc = c + dc_of(a);
-                mv = in_grid(nr, nc, S) && Gc(l, nr * S + nc) == C_EMPTY;
-                if (mv) { seen = (VIS(l, nr) >> nc) & 1u; if (seen) ++rev; else ++cap; }
-                else ++pen;
-            }
-            __syncthreads();
-            if (mv && sl == 0) {
-                VIS(l, nr) |= (1u << nc);
-                Gc(l, r * S + c) = C_EMPTY; Gc(l, nr * S + nc) = C_AGENT; AR(l, i) = (int16_t)nr; AC(l, i) = (int16_t)nc;
-            }
-            __syncthreads();
-        }
-        const int total = p.total_capture[b] + cap;
-        double fin = 0.0;
-        if (total == p.n_empty) { fin = p.final_reward; done = 1; }     // :381-385
-        if (step_count >= p.max_steps) { succ = done ? 1 : 0; done = 1; }   // :388-393
-        if (sl == 0 && commit) p.total_capture[b] = total;
-        // get_reward (:299-317), left-to-right; term_k[count] = coef_k * (count / N) tabulated on the host in f64
-        const double *T = p.rew_lut;
-        reward = p.step_cost + T[cap];
-        reward = reward + T[(N + 1) + mov];
-        reward = reward + T[2 * (N + 1) + pen];
-        reward = reward + T[3 * (N + 1) + lazy];
-        reward = reward + T[4 * (N + 1) + rev];
-        reward = reward + fin;
-        det0 = cap; det1 = mov; det2 = pen; det3 = lazy; det4 = rev; det5 = fin != 0.0;
-    }
-
-    if (step_count >= p.mpl) done = 1;                                   // vec_env_executor.py:33-34
-    if (sl == 0 && commit) {
-        if (o.reward) o.reward[b] = (float)reward;
-        if (o.reward_f64) o.reward_f64[b] = reward;
-        if (o.done) o.done[b] = (uint8_t)done;
-        if (o.path_len) o.path_len[b] = done ? step_count : 0;
-        if (o.details) {
-            int32_t *dd = o.details + (size_t)b * 6;
-            dd[0] = det0; dd[1] = det1; dd[2] = det2; dd[3] = det3; dd[4] = det4; dd[5] = det5;
-        }
-        p.rng_step[b] = rng.step + 1;
-    }
-    __syncthreads();
-    if (p.stop == 6) return;
-    // auto-reset (:36-43): groups whose env finished re-spawn and emit the reset observation
-    do_reset<SCEN, LPE>(p, l, rng, tape, b, g, done != 0);
-    if (done) step_count = 0;
-    if (!commit || p.stop == 7) return;
-    if (sl == 0) {
-        if (done && SCEN == CM_CO) p.total_capture[b] = 0;
-        p.step_count[b] = step_count;
-        p.success[b] = succ;
-        if (o.success) o.success[b] = succ;
-    }
-    emit<SCEN, LPE>(p, l, rng, tape, o, b, g, step_count, done ? 1 : 0);
+    const int grp = threadIdx.x / LPE;
+    env_body<SCEN, LPE>(p, actions, nullptr, tape, out, reset_only, grp, blockIdx.x * G + grp, true, 0);
 }
 
 __global__ void fill_const_kernel(float *adj, float *ch, int B, int N, int L, int channel) {
