@@ -83,6 +83,9 @@ _SIGNATURES = {
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "cm_critic_forward": (C.c_int, [C.POINTER(CriticWeights), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p]),
+    "cm_rollout_step": (C.c_int, [C.c_void_p, C.POINTER(PolicyWeights), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_uint64, C.c_int32, C.c_uint32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.POINTER(RngTape), C.POINTER(StepOut), C.c_void_p]),
     "cm_policy_pack_bytes": (C.c_size_t, [C.POINTER(PolicyWeights)]),
     "cm_policy_pack": (C.c_int, [C.POINTER(PolicyWeights), C.c_void_p, C.c_void_p]),
     "cm_critic_pack_bytes": (C.c_size_t, [C.POINTER(CriticWeights)]),

@@ -212,7 +212,7 @@ extern "C" int cm_env_fill_constants(cm_env_t h, float *dist_adj, float *channel
     return CM_OK;
 }
 
-static int check_tape(const cm_env *h, const cm_rng_tape *tape, bool is_reset) {
+int cm::check_tape(const cm_env *h, const cm_rng_tape *tape, bool is_reset) {
     if (h->cfg.rng_mode != CM_RNG_TAPE) return CM_OK;
     if (!tape) return set_error(CM_ERR_ARG, "rng_mode is TAPE but no tape was passed");
     if (!tape->spawn || tape->spawn_cap <= 0) return set_error(CM_ERR_ARG, "tape.spawn required in tape mode");

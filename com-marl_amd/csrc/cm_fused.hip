@@ -1,0 +1,98 @@
+// cm_fused.hip - one rollout step in ONE launch: the Comm-DP policy forward + sample of a workgroup's envs
+// (cm_policy_mfma_dev.h, reference: comm_categorical_mlp_policy.py:98-119) followed, in the same workgroup, by the
+// env step of those envs on the sampled actions (cm_env_dev.h, reference: vec_env_executor.py:19-45 over
+// predator_prey.py:494-519 / coverage.py:319-401 + env_communication.py:91-157).
+//
+// Why: at the headline config the stand-alone env kernel runs one wave per SIMD on a quarter of the machine and is
+// pure dependent-instruction latency (~12 us for ~2500 instructions per wave), and the policy kernel leaves issue
+// slots free whenever its waves wait on the matrix pipe.  Inside one workgroup the env phase of one workgroup
+// overlaps the matrix phases of its CU neighbour, the actions go from the sampler to the env step through LDS, and a
+// step costs one launch / one grid drain instead of two.  Results are bit-identical to cm_policy_forward followed by
+// cm_env_step (same device bodies, same Philox counters); tests/test_hip_fused_parity.py checks exactly that.
+#include <stdlib.h>
+
+#include "cm_env_dev.h"
+#include "cm_policy_mfma_dev.h"
+
+namespace cm {
+
+template <int SCEN, int LPE, int KPAD, int MAXMK>
+__global__ __launch_bounds__(mf::TPB) void rollout_step_kernel(mf::FwdArgs a, mf::TrunkW tw, mf::PolHead ph, EnvDev p,
+                                                               cm_rng_tape tape, cm_step_out out, int act_off) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    int32_t *act = reinterpret_cast<int32_t *>(lds + act_off);           // [EPB*N] sampled actions, behind the policy tiles
+    mf::fwd_body<0, KPAD, MAXMK>(a, tw, ph, mf::CritHead{}, lds, blockIdx.x, act);
+    __syncthreads();                                                     // actions visible; the policy tiles are dead
+    const int grp = threadIdx.x / LPE;
+    const int envs = min(a.EPB, a.S - (int)blockIdx.x * a.EPB);
+    const bool live = grp < envs;
+    env_body<SCEN, LPE>(p, nullptr, act + (live ? grp : 0) * p.N, tape, out, 0, grp, blockIdx.x * a.EPB + (live ? grp : 0), live, 0);
+}
+
+template <int SCEN, int LPE, int KPAD, int MAXMK>
+static int launch_fused(mf::FwdArgs a, const mf::TrunkW &tw, const mf::PolHead &ph, const cm_env *h, const cm_rng_tape &t,
+                        const cm_step_out &out, void *stream) {
+    const EnvDev &d = h->dev;
+    a.EPB = mf::pick_epb(a.N);
+    constexpr int GROUPS = mf::TPB / LPE;
+    if (a.EPB > GROUPS) return 1;                                        // more envs per workgroup than env groups
+    const int rows_cap = (a.EPB * a.N + 15) & ~15;
+    const size_t pol_floats = mf::lds_floats(rows_cap, a.EPB, a.N);
+    const size_t env_bytes = (size_t)d.lds_env * GROUPS;
+    if (env_bytes > pol_floats * sizeof(float)) return 1;                // env area would reach into the action array
+    const size_t lds = (pol_floats + (size_t)a.EPB * a.N) * sizeof(float);
+    if (lds > 160 * 1024) return 1;
+    static bool attr_set = false;
+    if (!attr_set) {
+        CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_step_kernel<SCEN, LPE, KPAD, MAXMK>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const int blocks = (a.S + a.EPB - 1) / a.EPB;
+    hipLaunchKernelGGL((rollout_step_kernel<SCEN, LPE, KPAD, MAXMK>), dim3(blocks), dim3(mf::TPB), lds, (hipStream_t)stream, a, tw, ph,
+                       d, t, out, (int)pol_floats);
+    CM_HIP(hipGetLastError());
+    return CM_OK;
+}
+
+}  // namespace cm
+
+using namespace cm;
+
+// COMMARL_FUSED=0 disables the fused step (A/B timing): the entry point then reports "not available"
+static bool fused_enabled() {
+    static const bool v = [] { const char *e = getenv("COMMARL_FUSED"); return !(e && e[0] == '0'); }();
+    return v;
+}
+
+extern "C" int cm_rollout_step(cm_env_t h, const cm_policy_weights *w, const float *obs, const float *avail,
+                               const float *dist_adj, const float *channels, uint64_t seed, int32_t env_id_offset,
+                               uint32_t policy_step, const uint32_t *policy_step_base, int32_t greedy, int32_t *actions,
+                               float *probs, float *attn, const cm_rng_tape *tape, const cm_step_out *out, void *stream) {
+    if (!h || !w || !obs || !out) return set_error(CM_ERR_ARG, "cm_rollout_step: null argument");
+    const EnvDev &d = h->dev;
+    if (w->n_agents != d.N || w->d != d.d || w->n_hops != d.L)
+        return set_error(CM_ERR_ARG, "cm_rollout_step: policy shape (n_agents, d, n_hops) does not match the env handle");
+    if (!fused_enabled() || !w->mfma_pack || !policy_shape_ok(w)) return 1;
+    if (int rc = check_tape(h, tape, false)) return rc;
+    cm_rng_tape t{};
+    if (tape) t = *tape;
+    mf::FwdArgs a{};
+    a.S = d.B; a.N = d.N; a.d = d.d; a.L = d.L;
+    a.obs = obs; a.avail = avail; a.adj = dist_adj; a.chan = channels;
+    a.key0 = (uint32_t)seed; a.key1 = (uint32_t)(seed >> 32); a.policy_step = policy_step; a.step_base = policy_step_base;
+    a.env_id_offset = env_id_offset; a.greedy = greedy; a.no_residual = w->no_residual;
+    a.actions = actions; a.probs = probs; a.attn = attn;
+    const int kpad = mf::kpad_of(d.d);
+    const mf::PackLayout lo = mf::pack_layout(kpad, d.L, true);
+    const float *P = w->mfma_pack;
+    const mf::TrunkW tw{ P + lo.enc1, w->enc_b1, P + lo.enc2, w->enc_b2, P + lo.attn, P + lo.gcn, w->gcn_b };
+    const mf::PolHead ph{ P + lo.x1, w->hd_b1, P + lo.h2, w->hd_b2, P + lo.h3, w->hd_b3, P + lo.h4, w->hd_b4, w->n_act };
+    const int mk = d.N < 32 ? 0 : (d.N <= 80 ? 25 : 64);                 // as mf::dispatch
+    // instantiations: the four BASELINE shapes (PP sen1 small teams; CO sen2 mid teams; PP / CO sen2 large teams)
+    if (d.scen == CM_PP && d.lpe == 16 && kpad == 32 && mk == 0) return launch_fused<CM_PP, 16, 32, 0>(a, tw, ph, h, t, *out, stream);
+    if (d.scen == CM_CO && d.lpe == 64 && kpad == 80 && mk == 0) return launch_fused<CM_CO, 64, 80, 0>(a, tw, ph, h, t, *out, stream);
+    if (d.scen == CM_PP && d.lpe == 64 && kpad == 64 && mk == 25) return launch_fused<CM_PP, 64, 64, 25>(a, tw, ph, h, t, *out, stream);
+    if (d.scen == CM_CO && d.lpe == 64 && kpad == 80 && mk == 25) return launch_fused<CM_CO, 64, 80, 25>(a, tw, ph, h, t, *out, stream);
+    return 1;
+}

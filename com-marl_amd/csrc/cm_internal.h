@@ -56,3 +56,7 @@ struct cm_env {
     void *arena;              // one hipMalloc for all state
     size_t arena_bytes;
 };
+
+namespace cm {
+int check_tape(const cm_env *h, const cm_rng_tape *tape, bool is_reset);   // cm_env.hip: tape pointers the config needs
+}

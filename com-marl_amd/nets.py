@@ -497,6 +497,24 @@ class CommCategoricalMLPPolicy(CommBaseNet):
                 L.current_stream()), "cm_policy_forward")
         return actions, probs, attn
 
+    @torch.no_grad()
+    def step_fused(self, env_batch, obs, dist_adj, channels, step_out, greedy=False, out_actions=None, out_probs=None,
+                   out_attn=None, policy_step=0, step_base=None, env_id_offset=None, tape=None):
+        """One sampler iteration in ONE launch (cm_rollout_step): this policy's forward + sample on `obs`, then the env
+        step of `env_batch` on the sampled actions, results into `step_out` (an _lib.StepOut of device pointers).
+        Returns False - having done nothing - when the library has no fused kernel for this shape."""
+        w = self._weights_struct()
+        with torch.cuda.device(obs.device):
+            rc = L.lib().cm_rollout_step(
+                env_batch._h, C.byref(w), L.ptr(obs), None, L.ptr(dist_adj), L.ptr(channels), self.seed,
+                self.env_id_offset if env_id_offset is None else int(env_id_offset), policy_step & 0xFFFFFFFF,
+                L.ptr(step_base), int(greedy), L.ptr(out_actions), L.ptr(out_probs), L.ptr(out_attn),
+                C.byref(tape) if tape is not None else None, C.byref(step_out), L.current_stream())
+        if rc == 1:
+            return False
+        L.check(rc, "cm_rollout_step")
+        return True
+
     def get_actions(self, obs_n, avail_actions_n, dist_adj, channels, greedy=False):
         """numpy in / numpy out, as the reference sampler calls it (:98-119)."""
         dev = next(self.parameters()).device

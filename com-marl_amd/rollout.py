@@ -2,7 +2,8 @@
 CentralizedMAOnPolicyVectorizedSampler.obtain_samples (com_marl/sampler/
 centralized_ma_on_policy_vectorized_sampler.py:119-232) for B envs at once.
 
-One step = two kernel launches, no host synchronisation and no copies:
+One step = one fused launch (cm_rollout_step) where the library has a fused kernel for the shape, else two kernel
+launches; either way no host synchronisation and no copies:
     policy forward + sample  (cm_policy_forward)  reads  obs[t], dist_adj[t], channels[t]
                                                    writes actions[t], probs[t], attn[t]
     env step + auto-reset    (cm_env_step)        reads  actions[t]
@@ -40,7 +41,7 @@ class _Parts:
 
 
 class RolloutEngine:
-    def __init__(self, env, policy, horizon, store_attn=True, store_probs=True):
+    def __init__(self, env, policy, horizon, store_attn=True, store_probs=True, fused=True):
         """env: envs.GridEnvBatch, or a list of shards of one batch (then every shard runs its own
         policy -> env chain on its own HIP stream: the chains are independent, so kernels of different
         shards overlap and their phases drift apart instead of contending in lockstep).
@@ -74,6 +75,7 @@ class RolloutEngine:
         self.channels = None if env.ch_const else z(H + 1, B, Lh, N, N)
         self.step_base = torch.zeros(1, dtype=i32, device=dev)      # device-side Philox counter base (uint32 bits)
         self._graphs = {}
+        self._fused = None if fused else False              # None = try the fused step, False = two launches per step
         self.t = 0
 
     # ------------------------------------------------------------------------------------------
@@ -103,6 +105,20 @@ class RolloutEngine:
     def _step_part(self, k, t, greedy):
         part, (lo, hi) = self.parts[k], self.bounds[k]
         nb = hi - lo
+        if self._fused is not False and hasattr(self.policy, "step_fused"):
+            # policy forward + sample + env step of this shard in one launch (cm_rollout_step); shapes without a fused
+            # kernel report "not available" once and the two-launch path below is used from then on
+            ok = self.policy.step_fused(
+                part, self.obs[t][lo:hi].view(nb, -1),
+                None if self.dist_adj is None else self.dist_adj[t][lo:hi],
+                None if self.channels is None else self.channels[t][lo:hi],
+                part._out(self._out(t, lo, hi)), greedy=greedy, out_actions=self.actions[t][lo:hi],
+                out_probs=None if self.probs is None else self.probs[t][lo:hi],
+                out_attn=None if self.attn is None else self.attn[t][lo:hi],
+                policy_step=t, step_base=self.step_base, env_id_offset=self.id0 + lo)
+            self._fused = ok
+            if ok:
+                return
         self.policy.act_device(
             self.obs[t][lo:hi].view(nb, -1), None,
             None if self.dist_adj is None else self.dist_adj[t][lo:hi],

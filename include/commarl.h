@@ -191,6 +191,18 @@ int cm_policy_forward(const cm_policy_weights *w, int32_t n_samples, const float
 int cm_critic_forward(const cm_critic_weights *w, int32_t n_samples, const float *obs, const float *dist_adj,
                       const float *channels, float *values, void *stream);
 
+/* One rollout step in ONE launch: cm_policy_forward over the B envs of `h` followed, inside the same workgroups, by
+ * cm_env_step on the sampled actions (which travel through LDS and are also written to `actions`): what one iteration
+ * of the sampler loop does (centralized_ma_on_policy_vectorized_sampler.py:133-141).  Arguments and results are those
+ * of the two calls (n_samples is the handle's B; obs / dist_adj / channels are the CURRENT step's inputs, `out` receives
+ * the next step's), bit-identical to calling them back to back.
+ * Returns 0 on success, < 0 on error, and 1 - having done nothing - when this (scenario, team size, obs dim) has no
+ * fused instantiation, no operand pack was supplied, or COMMARL_FUSED=0: call the two entry points instead. */
+int cm_rollout_step(cm_env_t h, const cm_policy_weights *w, const float *obs, const float *avail,
+                    const float *dist_adj, const float *channels, uint64_t seed, int32_t env_id_offset,
+                    uint32_t policy_step, const uint32_t *policy_step_base, int32_t greedy, int32_t *actions,
+                    float *probs, float *attn, const cm_rng_tape *tape, const cm_step_out *out, void *stream);
+
 /* Plain row-wise MLPs: the non-communicating policies and the Gaussian baseline of the reference's Obs-DP / CENT
  * runners.  Layer l:  y = x . wt[l] + b[l]  (wt TRANSPOSED [in,out] as above), followed by tanh
  * when bit l of tanh_mask is set.  First layer at most 128 outputs; any layer at most 1024. */

@@ -1,0 +1,91 @@
+"""cm_rollout_step (policy forward + sample + env step in ONE launch) against the two-launch path: same device
+bodies, same Philox counters -> every trajectory buffer must be bit-identical, for every BASELINE shape, with ragged
+batch sizes (partial workgroups), auto-resets inside the window, greedy and sampled actions."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = {
+    # name: (scenario, map, sen, N, M, load, loss, B, steps, mpl)
+    "pp_map10": ("pp", 10, 1, 4, 4, 2, 0.0, 203, 40, 9),
+    "co_map20": ("co", 20, 2, 24, 0, 2, 0.0, 7, 14, 6),
+    "pp_map30": ("pp", 30, 2, 72, 72, 4, 0.0, 3, 8, 5),
+    "co_map30_iid": ("co", 30, 2, 54, 0, 2, 0.3, 3, 8, 5),
+}
+
+
+def _params(scen, map_, sen, N, M, load, loss, mpl):
+    pp = scen == "pp"
+    return dict(load=load, max_env_steps=mpl, capture_reward=10 if pp else 2, step_cost=0.1 if pp else 0, rm=0,
+                penalty=0 if pp else 1, revisit_penalty=0.5, lazy_penalty=1, grid_size=map_, Rsen=sen, n_agents=N,
+                n_preys=M, n_gcn_layers=2, mode="train", trRcom=9, trpl=loss, obstComplex="Easy", add_clock=0)
+
+
+def _run(torch, shape, fused, greedy):
+    from com_marl_amd import envs as E, nets
+    from com_marl_amd.rollout import RolloutEngine
+    scen, map_, sen, N, M, load, loss, B, steps, mpl = SHAPES[shape]
+    env = E.GridEnvBatch(scen, _params(scen, map_, sen, N, M, load, loss, mpl), B, device="cuda:0", seed=3,
+                         max_steps=mpl if scen == "pp" else 400, max_path_length=mpl, env_id_offset=11)
+    spec = E.EnvSpec(E._Box(np.zeros(env.d * N), np.ones(env.d * N)), E._Discrete(5))
+    torch.manual_seed(3)
+    pol = nets.CommCategoricalMLPPolicy(spec, n_agents=N, device="cuda:0")
+    pol.set_rng(3)
+    eng = RolloutEngine(env, pol, steps, fused=fused)
+    eng.reset()
+    for t in range(steps):
+        eng.step(t, greedy=greedy)
+    torch.cuda.synchronize()
+    env.check_status()
+    bufs = {k: getattr(eng, k) for k in ("obs", "actions", "probs", "attn", "reward", "reward64", "done", "details",
+                                         "prey_alive", "success", "path_len", "dist_adj", "channels")}
+    out = {k: v.cpu().numpy() for k, v in bufs.items() if v is not None}
+    out["state"] = env.get_state()
+    return out, eng._fused
+
+
+@pytest.mark.parametrize("greedy", [False, True], ids=["sample", "greedy"])
+@pytest.mark.parametrize("shape", sorted(SHAPES))
+def test_fused_step_is_bit_identical_to_two_launches(shape, greedy):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need the MI355X")
+    a, used = _run(torch, shape, True, greedy)
+    assert used is True, "the library reported no fused kernel for a BASELINE shape"
+    b, used_b = _run(torch, shape, False, greedy)
+    assert used_b is False
+    assert a["done"].any(), "the window should contain auto-resets"
+    for k in sorted(b):
+        if k == "state":
+            for kk in b[k]:
+                np.testing.assert_array_equal(a[k][kk], b[k][kk], err_msg=f"state.{kk}")
+        else:
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+
+
+def test_fused_entry_point_reports_unavailable_and_errors():
+    import ctypes as C
+    import torch
+    from com_marl_amd import _lib as L, envs as E, nets
+    # CO sen1 (d = 29): no fused instantiation -> 1, nothing done, the engine falls back
+    p = _params("co", 10, 1, 3, 0, 2, 0.0, 8)
+    env = E.GridEnvBatch("co", p, 5, device="cuda:0", seed=1, max_path_length=8)
+    spec = E.EnvSpec(E._Box(np.zeros(env.d * 3), np.ones(env.d * 3)), E._Discrete(5))
+    pol = nets.CommCategoricalMLPPolicy(spec, n_agents=3, device="cuda:0")
+    from com_marl_amd.rollout import RolloutEngine
+    eng = RolloutEngine(env, pol, 4)
+    eng.reset()
+    for t in range(4):
+        eng.step(t)
+    torch.cuda.synchronize()
+    env.check_status()
+    assert eng._fused is False and int(env.get_state()["step_count"].max()) == 4
+    # shape mismatch between handle and weights is an error, not a silent fallback
+    spec4 = E.EnvSpec(E._Box(np.zeros(env.d * 4), np.ones(env.d * 4)), E._Discrete(5))
+    pol4 = nets.CommCategoricalMLPPolicy(spec4, n_agents=4, device="cuda:0")
+    w = pol4._weights_struct()
+    so = env._out()
+    rc = L.lib().cm_rollout_step(env._h, C.byref(w), env.obs.data_ptr(), None, None, None, 1, 0, 0, None, 0, None, None,
+                                 None, None, C.byref(so), None)
+    assert rc == -1 and b"does not match" in L.lib().cm_last_error()
