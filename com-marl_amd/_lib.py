@@ -53,6 +53,11 @@ class CriticWeights(C.Structure):
                                   "dec_b1", "dec_w2t", "dec_b2", "mfma_pack")]
 
 
+class ChunkStrides(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("obs", "actions", "probs", "attn", "reward", "reward_f64", "done", "details",
+                                         "dist_adj", "channels", "prey_alive", "success", "path_len")]
+
+
 MLP_MAX_LAYERS = 6
 
 
@@ -86,6 +91,9 @@ _SIGNATURES = {
     "cm_rollout_step": (C.c_int, [C.c_void_p, C.POINTER(PolicyWeights), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_uint64, C.c_int32, C.c_uint32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.POINTER(RngTape), C.POINTER(StepOut), C.c_void_p]),
+    "cm_rollout_chunk": (C.c_int, [C.c_void_p, C.POINTER(PolicyWeights), C.c_int32, C.POINTER(ChunkStrides), C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_uint32, C.c_void_p, C.c_int32,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(StepOut), C.c_void_p]),
     "cm_policy_pack_bytes": (C.c_size_t, [C.POINTER(PolicyWeights)]),
     "cm_policy_pack": (C.c_int, [C.POINTER(PolicyWeights), C.c_void_p, C.c_void_p]),
     "cm_critic_pack_bytes": (C.c_size_t, [C.POINTER(CriticWeights)]),

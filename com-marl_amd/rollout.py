@@ -12,9 +12,13 @@ The trajectory buffers are time-major [H(+1), B, ...] in HBM, so every step read
 contiguous [B, ...] slabs and the kernels write straight into them (zero-copy).  A chunk of
 steps can be captured into a hipGraph and replayed (the launch-bound regime at 4096 x N=4).
 """
+import contextlib
+
 import torch
 
 from . import _lib as L
+
+_null = contextlib.nullcontext
 
 
 class _Parts:
@@ -41,7 +45,7 @@ class _Parts:
 
 
 class RolloutEngine:
-    def __init__(self, env, policy, horizon, store_attn=True, store_probs=True, fused=True):
+    def __init__(self, env, policy, horizon, store_attn=True, store_probs=True, fused=True, persistent=False):
         """env: envs.GridEnvBatch, or a list of shards of one batch (then every shard runs its own
         policy -> env chain on its own HIP stream: the chains are independent, so kernels of different
         shards overlap and their phases drift apart instead of contending in lockstep).
@@ -75,7 +79,14 @@ class RolloutEngine:
         self.channels = None if env.ch_const else z(H + 1, B, Lh, N, N)
         self.step_base = torch.zeros(1, dtype=i32, device=dev)      # device-side Philox counter base (uint32 bits)
         self._graphs = {}
+        # fused: eager step() calls use cm_rollout_step (one launch instead of two: the host-bound sampler / eval loops
+        # gain; captured chunks keep the two-kernel form, which replays ~2 % faster because the env kernels of one
+        # shard fill the tail of the other's policy kernel).  persistent: run_chunk as ONE cm_rollout_chunk launch per
+        # shard - bit-identical, but measured slower on MI355X (the drifting workgroups thrash the instruction cache:
+        # 52 us vs 36 us per step at the headline config), so it is opt-in.
         self._fused = None if fused else False              # None = try the fused step, False = two launches per step
+        self._persistent = bool(persistent and fused)
+        self._capturing = False
         self.t = 0
 
     # ------------------------------------------------------------------------------------------
@@ -105,7 +116,7 @@ class RolloutEngine:
     def _step_part(self, k, t, greedy):
         part, (lo, hi) = self.parts[k], self.bounds[k]
         nb = hi - lo
-        if self._fused is not False and hasattr(self.policy, "step_fused"):
+        if self._fused is not False and not self._capturing and hasattr(self.policy, "step_fused"):
             # policy forward + sample + env step of this shard in one launch (cm_rollout_step); shapes without a fused
             # kernel report "not available" once and the two-launch path below is used from then on
             ok = self.policy.step_fused(
@@ -160,8 +171,48 @@ class RolloutEngine:
         if self.channels is not None:
             self.channels[0].copy_(self.channels[self.H])
 
+    def _strides(self):
+        e = self.env
+        B, N, M, d, Lh, A = e.B, e.N, max(e.M, 1), e.d, e.Lh, self.policy._action_dim
+        return L.ChunkStrides(obs=B * N * d, actions=B * N, probs=B * N * A, attn=B * N * N, reward=B, reward_f64=B,
+                              done=B, details=B * 6, dist_adj=B * N * N, channels=B * Lh * N * N, prey_alive=B * M,
+                              success=B, path_len=B)
+
+    def steps_fused(self, t0, n, greedy=False):
+        """Slots t0 .. t0+n-1 in one persistent launch per shard (cm_rollout_chunk); False when the library has no
+        fused kernel for this shape (nothing was launched)."""
+        if self._fused is False or not hasattr(self.policy, "chunk_fused") or getattr(self.parts[0].cfg, "rng_mode", 0) != L.RNG_PHILOX:
+            return False
+        st = self._strides()
+        self.fork()
+        for k, stream in enumerate(self.streams):
+            part, (lo, hi) = self.parts[k], self.bounds[k]
+            nb = hi - lo
+            with torch.cuda.stream(stream) if stream is not None else _null():
+                ok = self.policy.chunk_fused(
+                    part, n, st, self.obs[t0][lo:hi].view(nb, -1),
+                    None if self.dist_adj is None else self.dist_adj[t0][lo:hi],
+                    None if self.channels is None else self.channels[t0][lo:hi],
+                    part._out(self._out(t0, lo, hi)), greedy=greedy, out_actions=self.actions[t0][lo:hi],
+                    out_probs=None if self.probs is None else self.probs[t0][lo:hi],
+                    out_attn=None if self.attn is None else self.attn[t0][lo:hi],
+                    policy_step=t0, step_base=self.step_base, env_id_offset=self.id0 + lo)
+            if not ok:
+                assert k == 0, "fused chunk availability must not differ between shards"
+                self._fused = False
+                self.join()
+                return False
+        self.join()
+        self._fused = True
+        return True
+
     def run_chunk(self, use_graph=True):
-        """H steps filling every slot; with use_graph the chunk is one hipGraph replay."""
+        """H steps filling every slot: one persistent launch per shard where the library has a fused kernel for the
+        shape; otherwise H x (policy, env) launches - replayed from one hipGraph with use_graph."""
+        if self._persistent and self.steps_fused(0, self.H):
+            self.step_base.add_(self.H)
+            self._wrap()
+            return
         if not use_graph:
             self.fork()
             for t in range(self.H):
@@ -178,13 +229,17 @@ class RolloutEngine:
             self.join()
             torch.cuda.synchronize(self.env.device)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):   # NCCL's watchdog thread may touch HIP during capture
-                self.fork()
-                for t in range(self.H):
-                    self.step(t)
-                self.join()
-                self.step_base.add_(self.H)
-                self._wrap()
+            self._capturing = True
+            try:
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):   # NCCL's watchdog thread may touch HIP during capture
+                    self.fork()
+                    for t in range(self.H):
+                        self.step(t)
+                    self.join()
+                    self.step_base.add_(self.H)
+                    self._wrap()
+            finally:
+                self._capturing = False
             self._graphs["chunk"] = g
         self.policy.sync_weights()          # in-place refresh of the weight pack the graph points at
         g.replay()

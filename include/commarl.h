@@ -203,6 +203,20 @@ int cm_rollout_step(cm_env_t h, const cm_policy_weights *w, const float *obs, co
                     uint32_t policy_step, const uint32_t *policy_step_base, int32_t greedy, int32_t *actions,
                     float *probs, float *attn, const cm_rng_tape *tape, const cm_step_out *out, void *stream);
 
+/* n_steps consecutive rollout steps in ONE launch: step t = cm_rollout_step with every pointer advanced by t x its
+ * per-step stride (time-major trajectory buffers [T(+1), B, ...]: obs / dist_adj / channels are read at slot t and -
+ * through `out` - written at slot t + 1) and policy_step + t.  A workgroup keeps its envs for the whole chunk and no
+ * grid-wide synchronisation separates the steps, so env phases overlap other workgroups' matrix phases.  Production
+ * RNG only (tape mode is refused); no avail mask.  Results are bit-identical to n_steps calls of cm_rollout_step.
+ * Strides are in ELEMENTS of the respective buffer; unused outputs may have stride 0.  Returns as cm_rollout_step. */
+typedef struct cm_chunk_strides {
+    int64_t obs, actions, probs, attn, reward, reward_f64, done, details, dist_adj, channels, prey_alive, success, path_len;
+} cm_chunk_strides;
+int cm_rollout_chunk(cm_env_t h, const cm_policy_weights *w, int32_t n_steps, const cm_chunk_strides *strides,
+                     const float *obs, const float *dist_adj, const float *channels, uint64_t seed,
+                     int32_t env_id_offset, uint32_t policy_step, const uint32_t *policy_step_base, int32_t greedy,
+                     int32_t *actions, float *probs, float *attn, const cm_step_out *out, void *stream);
+
 /* Plain row-wise MLPs: the non-communicating policies and the Gaussian baseline of the reference's Obs-DP / CENT
  * runners.  Layer l:  y = x . wt[l] + b[l]  (wt TRANSPOSED [in,out] as above), followed by tanh
  * when bit l of tanh_mask is set.  First layer at most 128 outputs; any layer at most 1024. */

@@ -22,7 +22,7 @@ def _params(scen, map_, sen, N, M, load, loss, mpl):
                 n_preys=M, n_gcn_layers=2, mode="train", trRcom=9, trpl=loss, obstComplex="Easy", add_clock=0)
 
 
-def _run(torch, shape, fused, greedy):
+def _run(torch, shape, fused, greedy, chunked=False):
     from com_marl_amd import envs as E, nets
     from com_marl_amd.rollout import RolloutEngine
     scen, map_, sen, N, M, load, loss, B, steps, mpl = SHAPES[shape]
@@ -34,8 +34,11 @@ def _run(torch, shape, fused, greedy):
     pol.set_rng(3)
     eng = RolloutEngine(env, pol, steps, fused=fused)
     eng.reset()
-    for t in range(steps):
-        eng.step(t, greedy=greedy)
+    if chunked:          # two persistent launches: slots 0..2, then 3..steps-1
+        assert eng.steps_fused(0, 3, greedy=greedy) and eng.steps_fused(3, steps - 3, greedy=greedy)
+    else:
+        for t in range(steps):
+            eng.step(t, greedy=greedy)
     torch.cuda.synchronize()
     env.check_status()
     bufs = {k: getattr(eng, k) for k in ("obs", "actions", "probs", "attn", "reward", "reward64", "done", "details",
@@ -62,6 +65,47 @@ def test_fused_step_is_bit_identical_to_two_launches(shape, greedy):
                 np.testing.assert_array_equal(a[k][kk], b[k][kk], err_msg=f"state.{kk}")
         else:
             np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+
+
+@pytest.mark.parametrize("shape", sorted(SHAPES))
+def test_persistent_chunk_is_bit_identical_to_two_launches(shape):
+    """cm_rollout_chunk: n steps inside one launch (no grid-wide sync between steps) == n x (policy, env) launches."""
+    import torch
+    a, used = _run(torch, shape, True, False, chunked=True)
+    assert used is True
+    b, _ = _run(torch, shape, False, False)
+    assert a["done"].any()
+    for k in sorted(b):
+        if k == "state":
+            for kk in b[k]:
+                np.testing.assert_array_equal(a[k][kk], b[k][kk], err_msg=f"state.{kk}")
+        else:
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+
+
+def test_run_chunk_uses_the_persistent_kernel_and_matches_stepwise_launches():
+    import torch
+    from com_marl_amd import envs as E, nets
+    from com_marl_amd.rollout import RolloutEngine
+    scen, map_, sen, N, M, load, loss, B, steps, mpl = SHAPES["pp_map10"]
+    outs = []
+    for persistent in (True, False):
+        shards = [E.GridEnvBatch(scen, _params(scen, map_, sen, N, M, load, loss, mpl), 64, device="cuda:0", seed=3,
+                                 max_steps=mpl, max_path_length=mpl, env_id_offset=64 * k) for k in range(2)]
+        spec = E.EnvSpec(E._Box(np.zeros(shards[0].d * N), np.ones(shards[0].d * N)), E._Discrete(5))
+        torch.manual_seed(3)
+        pol = nets.CommCategoricalMLPPolicy(spec, n_agents=N, device="cuda:0")
+        pol.set_rng(3)
+        eng = RolloutEngine(shards, pol, 12, persistent=persistent)   # persistent is opt-in
+        eng.reset()
+        for _ in range(3):
+            eng.run_chunk(use_graph=False)      # (graph capture spends one extra warm-up step: not comparable slot by slot)
+        torch.cuda.synchronize()
+        eng.env.check_status()
+        assert eng._fused is True
+        outs.append([getattr(eng, k).cpu().numpy() for k in ("obs", "actions", "probs", "reward64", "done", "path_len")])
+    for x, y in zip(*outs):
+        np.testing.assert_array_equal(x, y)
 
 
 def test_fused_entry_point_reports_unavailable_and_errors():
