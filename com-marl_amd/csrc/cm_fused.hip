@@ -155,6 +155,8 @@ static int rollout_impl(cm_env_t h, const cm_policy_weights *w, const float *obs
     const mf::PolHead ph{ P + lo.x1, w->hd_b1, P + lo.h2, w->hd_b2, P + lo.h3, w->hd_b3, P + lo.h4, w->hd_b4, w->n_act };
     const int mk = d.N < 32 ? 0 : (d.N <= 80 ? 25 : 64);                 // as mf::dispatch
     // instantiations: the four BASELINE shapes (PP sen1 small teams; CO sen2 mid teams; PP / CO sen2 large teams)
+    const bool quad = d.N == 4 && mf::pick_epb(4) * 4 <= 32;
+    if (d.scen == CM_PP && d.lpe == 16 && kpad == 32 && quad) return launch_fused<CM_PP, 16, 32, -1>(a, tw, ph, h, t, *out, stream, chunk);
     if (d.scen == CM_PP && d.lpe == 16 && kpad == 32 && mk == 0) return launch_fused<CM_PP, 16, 32, 0>(a, tw, ph, h, t, *out, stream, chunk);
     if (d.scen == CM_CO && d.lpe == 64 && kpad == 80 && mk == 0) return launch_fused<CM_CO, 64, 80, 0>(a, tw, ph, h, t, *out, stream, chunk);
     if (d.scen == CM_PP && d.lpe == 64 && kpad == 64 && mk == 25) return launch_fused<CM_PP, 64, 64, 25>(a, tw, ph, h, t, *out, stream, chunk);

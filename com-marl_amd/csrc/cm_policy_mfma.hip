@@ -94,7 +94,8 @@ static int dispatch(const FwdArgs &a, const TrunkW &tw, const PolHead &ph, const
     // N x N products on MFMA from N = 32 up (measured: at N = 24 the padded 32 x 32 tiles lose to the VALU form)
     const int mk = a.N < 32 ? 0 : (a.N <= 80 ? 25 : 64);    // (row blocks) x (column blocks) of 16
     (void)nn;
-#define CM_FWD(K) (mk == 0 ? launch<HEAD, K, 0>(a, tw, ph, chd, stream) \
+    const bool quad = a.N == 4 && pick_epb(4) * 4 <= 32;    // teams of 4: the register-resident attention / aggregation kernel
+#define CM_FWD(K) (quad ? launch<HEAD, K, -1>(a, tw, ph, chd, stream) : mk == 0 ? launch<HEAD, K, 0>(a, tw, ph, chd, stream) \
                    : mk == 25 ? launch<HEAD, K, 25>(a, tw, ph, chd, stream) : launch<HEAD, K, 64>(a, tw, ph, chd, stream))
     switch (kpad) {      // obs dims of the reference scenarios: PP sen1 21, CO sen1 29, PP sen2 53, CO sen2 77 (+clock 78)
     case 32: return CM_FWD(32);

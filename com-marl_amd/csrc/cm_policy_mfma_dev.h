@@ -314,8 +314,11 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &a, const TrunkW &tw, con
     // first and every later operand is requested one or two phases before its use: the observation tile, then the
     // encoder weights; small vectors used deep inside the kernel (GCN biases, the sampler's step counter) ride along
     // here instead of exposing an L2 round trip in the middle of a phase.
-    constexpr bool EARLY = MAXMK == 0;                  // small teams have the registers to prefetch the head early
-    const bool quad_path = MAXMK == 0 && N == 4 && rows_cap <= 32;      // uniform over the grid
+    // MAXMK < 0 selects the register-resident path for teams of 4 (host guarantees N == 4 and <= 32 rows per
+    // workgroup): its own instantiation, so it neither carries the general path's code nor burdens it with the
+    // early head prefetch its free registers allow
+    constexpr bool quad_path = MAXMK < 0;
+    constexpr bool EARLY = quad_path;
     constexpr int OBSR = 8;
     const float *src = a.obs + (size_t)s0 * N * d;
     const int obs_total = RT * 16 * KPAD;
@@ -368,7 +371,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &a, const TrunkW &tw, con
     lds_barrier();
     if (a.stop == 3) return;
     CM_PROBE(3);
-    if (MAXMK == 0 && quad_path) {
+    if (quad_path) {
         const int c = lane & 15, g = lane >> 4, q = lane & 3;
         const bool diag = (c >> 2) == g;                                 // this lane's quad holds a diagonal block
         l_sq.template run<false>(E, SE, T, SE, RT, wave, lane);          // Q = E.Wa^T

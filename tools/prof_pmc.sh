@@ -7,7 +7,7 @@ TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmc_$TAG
 rocprofv3 --pmc $@ --output-format csv -d /tmp/pmc_$TAG -o p -- python3 $ROOT/bench.py --steps 40 --warmup 20 --streams 1 --no-graph --no-train-loop --no-cpu-baseline > $ROOT/gpurun_out/pmc_$TAG.log 2>&1
-python3 - "$TAG" <<'PY' > $ROOT/gpurun_out/pmc_$1.txt
+python3 - "$TAG" <<'PY' > $ROOT/gpurun_out/pmc_$TAG.txt
 import csv, glob, sys, collections
 tag = sys.argv[1]
 f = glob.glob(f"/tmp/pmc_{tag}/**/*counter_collection.csv", recursive=True)[0]
