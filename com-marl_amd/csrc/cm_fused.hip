@@ -153,7 +153,8 @@ static int rollout_impl(cm_env_t h, const cm_policy_weights *w, const float *obs
     const float *P = w->mfma_pack;
     const mf::TrunkW tw{ P + lo.enc1, w->enc_b1, P + lo.enc2, w->enc_b2, P + lo.attn, P + lo.gcn, w->gcn_b };
     const mf::PolHead ph{ P + lo.x1, w->hd_b1, P + lo.h2, w->hd_b2, P + lo.h3, w->hd_b3, P + lo.h4, w->hd_b4, w->n_act };
-    const int mk = d.N < 32 ? 0 : (d.N <= 80 ? 25 : 64);                 // as mf::dispatch
+    static const int mk_min = [] { const char *e = getenv("COMMARL_MK_MIN"); return e ? atoi(e) : 16; }();   // N x N products on MFMA tiles from 16 agents up
+    const int mk = d.N < mk_min ? 0 : (d.N <= 80 ? 25 : 64);                 // as mf::dispatch
     // instantiations: the four BASELINE shapes (PP sen1 small teams; CO sen2 mid teams; PP / CO sen2 large teams)
     const bool quad = d.N == 4 && mf::pick_epb(4) * 4 <= 32;
     if (d.scen == CM_PP && d.lpe == 16 && kpad == 32 && quad) return launch_fused<CM_PP, 16, 32, -1>(a, tw, ph, h, t, *out, stream, chunk);

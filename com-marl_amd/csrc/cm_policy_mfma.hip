@@ -92,7 +92,8 @@ static int dispatch(const FwdArgs &a, const TrunkW &tw, const PolHead &ph, const
     if (a.N > 128) return 1;             // N x N MFMA tiles are built for teams of up to 128 agents
     const int nn = a.N * a.N;
     // N x N products on MFMA from N = 32 up (measured: at N = 24 the padded 32 x 32 tiles lose to the VALU form)
-    const int mk = a.N < 32 ? 0 : (a.N <= 80 ? 25 : 64);    // (row blocks) x (column blocks) of 16
+    static const int mk_min = [] { const char *e = getenv("COMMARL_MK_MIN"); return e ? atoi(e) : 16; }();   // N x N products on MFMA tiles from 16 agents up
+    const int mk = a.N < mk_min ? 0 : (a.N <= 80 ? 25 : 64);    // (row blocks) x (column blocks) of 16
     (void)nn;
     const bool quad = a.N == 4 && pick_epb(4) * 4 <= 32;    // teams of 4: the register-resident attention / aggregation kernel
 #define CM_FWD(K) (quad ? launch<HEAD, K, -1>(a, tw, ph, chd, stream) : mk == 0 ? launch<HEAD, K, 0>(a, tw, ph, chd, stream) \
