@@ -19,14 +19,14 @@ class EnvCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "scenario", "n_envs", "n_agents", "n_preys", "grid", "rsen", "load", "max_steps", "max_path_length",
         "n_hops", "rcom", "channel", "obst_hard", "add_clock", "rng_mode", "env_id_offset")] + [
-        ("ploss", C.c_float), ("pgb", C.c_float), ("pbg", C.c_float), ("_pad", C.c_float)] + [
+        ("ploss", C.c_float), ("pgb", C.c_float), ("pbg", C.c_float), ("ge_flags", C.c_int32)] + [
         (n, C.c_double) for n in ("capture_reward", "step_cost", "move_cost", "penalty", "lazy_penalty",
                                   "revisit_penalty", "final_reward")] + [("seed", C.c_uint64)]
 
 
 class RngTape(C.Structure):
     _fields_ = [("prey", C.c_void_p), ("spawn", C.c_void_p), ("spawn_cap", C.c_int32), ("_pad", C.c_int32),
-                ("iid_u", C.c_void_p), ("ge_u", C.c_void_p)]
+                ("iid_u", C.c_void_p), ("ge_u", C.c_void_p), ("ge_init_u", C.c_void_p)]
 
 
 class StepOut(C.Structure):

@@ -103,6 +103,10 @@ extern "C" int cm_env_create(const cm_env_cfg *cfg, cm_env_t *out) {
     if (c.n_hops < 1 || c.n_hops > 8) return set_error(CM_ERR_ARG, "1 <= n_hops <= 8 required");
     if (c.max_steps < 1 || c.max_path_length < 1) return set_error(CM_ERR_ARG, "max_steps and max_path_length must be >= 1");
     if (c.channel < CM_CH_FC || c.channel > CM_CH_GE) return set_error(CM_ERR_ARG, "bad channel");
+    if (c.ge_flags < 0 || c.ge_flags > 5 || ((c.ge_flags >> 1) & 3) == 3) return set_error(CM_ERR_ARG, "bad ge_flags");
+    if ((c.ge_flags & 1) && ((c.ge_flags >> 1) & 3) == 2)
+        return set_error(CM_ERR_ARG, "GE: random initial state with one transition per env step (GE_INIT random + loss_apply 0) "
+                                     "is shape-inconsistent in the reference (env_communication.py:121) and not built");
     const int M = c.scenario == CM_PP ? c.n_preys : 0;
     if ((long)c.n_agents + M > (long)(S * S) / 2) return set_error(CM_ERR_ARG, "too many agents+preys for the grid");
 
@@ -116,6 +120,7 @@ extern "C" int cm_env_create(const cm_env_cfg *cfg, cm_env_t *out) {
     const int rc = (c.rcom + 1 >= c.grid) ? 0 : c.rcom;                 // env_communication.py:71-72
     d.adj_const = rc == 0; d.rc2 = 2 * rc * rc;
     d.channel = c.channel; d.ch_const = (c.channel == CM_CH_FC || c.channel == CM_CH_FL);
+    d.ge_flags = c.ge_flags;
     d.add_clock = c.add_clock; d.rng_mode = c.rng_mode; d.env_id_offset = c.env_id_offset;
     d.ploss = c.ploss; d.pgb = c.pgb; d.pbg = c.pbg;
     d.cap_rew = c.capture_reward; d.step_cost = c.step_cost; d.move_cost = c.move_cost; d.penalty = c.penalty;
@@ -219,6 +224,8 @@ int cm::check_tape(const cm_env *h, const cm_rng_tape *tape, bool is_reset) {
     if (!is_reset && h->dev.scen == CM_PP && h->dev.M > 0 && !tape->prey) return set_error(CM_ERR_ARG, "tape.prey required for PP steps");
     if (h->dev.channel == CM_CH_IID && !tape->iid_u) return set_error(CM_ERR_ARG, "tape.iid_u required for IID channel");
     if (h->dev.channel == CM_CH_GE && !tape->ge_u) return set_error(CM_ERR_ARG, "tape.ge_u required for GE channel");
+    if (h->dev.channel == CM_CH_GE && ((h->dev.ge_flags >> 1) & 3) == 2 && !tape->ge_init_u)
+        return set_error(CM_ERR_ARG, "tape.ge_init_u required for GE with a random initial state");
     return CM_OK;
 }
 

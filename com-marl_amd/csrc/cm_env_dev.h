@@ -274,14 +274,31 @@ __device__ __forceinline__ void emit(const EnvDev &p, const Lds l, const Rng rng
         float *ch = out.channels ? out.channels + (size_t)b * L * NN : nullptr;
         uint8_t *gs = p.ge_state + (size_t)b * NN;
         const uint32_t site = slot ? SITE_GE_RESET : SITE_GE_STEP;
-        const int l0 = slot ? 1 : 0;                                 // reset: hop 0 = all good, then L-1 transitions
+        // ge_flags bit 0 = loss_apply 0: one transition per ENV STEP shared by all hops (:144-149; at reset the initial
+        // state fills every hop, no draws, :108-123) instead of one per hop (:151-156; reset: hop 0 = initial state, then
+        // L-1 transitions, :124-141).  bits 1-2 = GE_INIT: good / bad / random (get_init_state, GE model :84-87).
+        const bool per_step = p.ge_flags & 1;
+        const int init_mode = (p.ge_flags >> 1) & 3;
+        const int l0 = slot ? 1 : 0, l1 = per_step ? 1 : L;
+        const float bad_rate = (float)((double)p.pgb / ((double)p.pgb + (double)p.pbg));
         for (int k0 = sl * 4; k0 < NN; k0 += LPE * 4) {
             uint8_t s[4];
+            if (slot) {
+                float ui[4] = { 1.0f, 1.0f, 1.0f, 1.0f };
+                if (init_mode == 2) {
+                    if (p.rng_mode == CM_RNG_TAPE) { for (int e = 0; e < 4; ++e) ui[e] = tape.ge_init_u[(size_t)b * NN + (k0 + e < NN ? k0 + e : NN - 1)]; }
+                    else uniform4(rng, SITE_GE_INIT, (uint32_t)k0, ui);
+                }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) s[e] = (k0 + e < NN) ? (slot ? (uint8_t)1 : gs[k0 + e]) : (uint8_t)0;
-            if (slot && ch)
-                for (int e = 0; e < 4; ++e) if (k0 + e < NN) ch[k0 + e] = 1.0f;
-            for (int hop = l0; hop < L; ++hop) {
+                for (int e = 0; e < 4; ++e)
+                    s[e] = (k0 + e < NN) ? (uint8_t)(init_mode == 0 ? 1 : (init_mode == 1 ? 0 : (ui[e] >= bad_rate))) : (uint8_t)0;
+                if (ch)
+                    for (int e = 0; e < 4; ++e) if (k0 + e < NN) ch[k0 + e] = (float)s[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s[e] = (k0 + e < NN) ? gs[k0 + e] : (uint8_t)0;
+            }
+            for (int hop = l0; hop < l1; ++hop) {
                 float ugb[4], ubg[4];
                 if (p.rng_mode == CM_RNG_TAPE) {
                     const float *u = tape.ge_u + (((size_t)b * 2 + slot) * L + hop) * 2 * NN;
@@ -302,6 +319,9 @@ __device__ __forceinline__ void emit(const EnvDev &p, const Lds l, const Rng rng
                     if (ch) ch[(size_t)hop * NN + k] = (float)s[e];
                 }
             }
+            if (per_step && ch)                                          // .expand(GCNHops, ...): all hops see one state
+                for (int hop = 1; hop < L; ++hop)
+                    for (int e = 0; e < 4; ++e) if (k0 + e < NN) ch[(size_t)hop * NN + k0 + e] = (float)s[e];
             for (int e = 0; e < 4; ++e) if (k0 + e < NN) gs[k0 + e] = s[e];
         }
     }

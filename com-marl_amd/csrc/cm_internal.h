@@ -22,6 +22,7 @@ int hip_fail(hipError_t e, const char *what);      // -> CM_ERR_HIP
 struct EnvDev {
     int scen, B, N, M, S, R, W, d, load, max_steps, mpl, L, rc2, channel, add_clock, n_empty, rng_mode, env_id_offset;
     int adj_const, ch_const;
+    int ge_flags;             // cm_env_cfg.ge_flags (bit 0: one GE transition per env step; bits 1-2: initial state)
     int lpe, lds_env;         // lanes per env (16/32/64) and LDS bytes per env
     int stop;                 // diagnostic (COMMARL_ENV_STOP): return after phase `stop`; 0 = run everything
     float rcp_d, rcp_W, rcp_N, rcp_WW, rcp_NN;   // float reciprocals for the exact fast division in the emit loops

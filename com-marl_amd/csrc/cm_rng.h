@@ -15,7 +15,7 @@
 namespace cm {
 
 enum : uint32_t { SITE_SPAWN = 1, SITE_PREY = 2, SITE_IID_STEP = 3, SITE_IID_RESET = 4, SITE_GE_STEP = 5,
-                  SITE_GE_RESET = 6, SITE_ACTION = 7 };
+                  SITE_GE_RESET = 6, SITE_ACTION = 7, SITE_GE_INIT = 8 };
 
 struct u32x4 { uint32_t x, y, z, w; };
 

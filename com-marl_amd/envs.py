@@ -67,6 +67,11 @@ def make_cfg(scenario, params, n_envs, *, seed=1, env_id_offset=0, rng_mode=L.RN
             raise ValueError(f"invalid Ploss value: pl={pl}")
     c.channel = L.CHANNELS[channel]
     c.ploss, c.pgb, c.pbg = float(pl), float(p.get("Pgb", 0.0196)), float(p.get("Pbg", 0.282))
+    # GE variants (env_communication.py:21,54-60,106-157): GE_INIT 1 good / 0 bad / else random; loss_apply 0 = one
+    # state transition per env step shared by all hops, 1 (default) = one per GCN hop
+    gi = p.get("GE_INIT", 1)
+    la = p.get("loss_apply", 1)
+    c.ge_flags = (0 if (la is None or la) else 1) | ((0 if gi in (1, None) else (1 if gi == 0 else 2)) << 1)
     c.rcom = int(p.get(f"{pref}Rcom", 9))
     c.obst_hard = int(p.get("obstComplex", "Easy") == "Hard")
     c.add_clock = int(p.get("add_clock") or 0)
@@ -151,8 +156,10 @@ class GridEnvBatch:
             return None if a is None else torch.as_tensor(np.ascontiguousarray(a), dtype=dt).to(dev).contiguous()
         prey, spawn = up(tape.get("prey"), torch.uint8), up(tape.get("spawn"), torch.int32)
         iid, ge = up(tape.get("iid_u"), torch.float32), up(tape.get("ge_u"), torch.float32)
-        self._keep = (prey, spawn, iid, ge)
-        return L.RngTape(L.ptr(prey), L.ptr(spawn), 0 if spawn is None else spawn.shape[1], 0, L.ptr(iid), L.ptr(ge))
+        gi = up(tape.get("ge_init_u"), torch.float32)
+        self._keep = (prey, spawn, iid, ge, gi)
+        return L.RngTape(L.ptr(prey), L.ptr(spawn), 0 if spawn is None else spawn.shape[1], 0, L.ptr(iid), L.ptr(ge),
+                         L.ptr(gi))
 
     def reset_all(self, tape=None, out=None):
         t = self._tape(tape)

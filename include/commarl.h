@@ -64,7 +64,11 @@ typedef struct cm_env_cfg {
     int32_t rng_mode;        /* CM_RNG_PHILOX production / CM_RNG_TAPE parity */
     int32_t env_id_offset;   /* global id of local env 0: rank r of k owns [r*B, (r+1)*B) */
     float ploss, pgb, pbg;
-    float _pad;
+    int32_t ge_flags;        /* GE channel variants (env_communication.py:106-157), 0 = the runners' defaults:
+                                bit 0 set  = loss_apply 0: ONE state transition per env step shared by all hops (else one per hop);
+                                bits 1-2   = GE_INIT: 0 all links good, 1 all bad, 2 random with the stationary bad rate
+                                             Pgb/(Pgb+Pbg) (not together with bit 0: the reference's state is shape-
+                                             inconsistent for that pair, :121) */
     double capture_reward, step_cost, move_cost, penalty, lazy_penalty, revisit_penalty, final_reward;
     uint64_t seed;
 } cm_env_cfg;
@@ -78,6 +82,7 @@ typedef struct cm_rng_tape {
     int32_t _pad;
     const float *iid_u;      /* [B,2,L,N,N]   torch.rand (env_communication.py:212) */
     const float *ge_u;       /* [B,2,L,2,N,N] torch.rand (gilbert_elliot_loss_model.py:138,142) */
+    const float *ge_init_u;  /* [B,N,N] torch.rand of get_init_state (:84-87), GE_INIT random only */
 } cm_rng_tape;
 
 /* What VecEnvExecutor.step returns + the env attributes the sampler reads each step

@@ -37,7 +37,7 @@ void cmo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 }
 
 enum { SITE_SPAWN = 1, SITE_PREY = 2, SITE_IID_STEP = 3, SITE_IID_RESET = 4, SITE_GE_STEP = 5, SITE_GE_RESET = 6,
-       SITE_ACTION = 7 };
+       SITE_ACTION = 7, SITE_GE_INIT = 8 };
 
 static inline float u32_to_unit_f32(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
 static inline uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
@@ -248,18 +248,32 @@ static void comm_channels(env_view *e, rng_ctx *rc, int slot, float *ch) {
                     ch[k] = (u >= e->cfg->ploss) ? 1.0f : 0.0f;
                 }
         break;
-    case CMO_CH_GE: {                                                   /* :106-157, GE_INIT=1, loss_apply=1 */
+    case CMO_CH_GE: {                                                   /* env_communication.py:106-157 */
+        /* ge_flags bit 0 = loss_apply == 0: one transition per ENV STEP shared by all hops (:144-149; reset :108-123:
+         * the initial state for every hop, no draws) instead of one per GCN hop (:151-156; reset :124-141: hop 0 = the
+         * initial state, then L-1 transitions).  bits 1-2 = GE_INIT: good (ones), bad (zeros) or random
+         * (get_init_state, gilbert_elliot_loss_model.py:84-87: rand(n,n) >= Pgb/(Pgb+Pbg), no identity added). */
         uint8_t cur[MAXN * MAXN / 4], nxt[MAXN * MAXN / 4];
         float ugb[MAXN * MAXN / 4], ubg[MAXN * MAXN / 4];
-        int l0 = 0;
-        if (slot == 1) {                                                /* step_count == 0: state = ones, then L-1 hops */
-            memset(cur, 1, (size_t)NN);
-            for (int k = 0; k < NN; ++k) ch[k] = 1.0f;
+        const int per_step = e->cfg->ge_flags & 1, init_mode = (e->cfg->ge_flags >> 1) & 3;
+        int l0 = 0, l1 = per_step ? 1 : L;
+        if (slot == 1) {                                                /* step_count == 0 */
+            if (init_mode == 2) {
+                const float bad_rate = (float)((double)e->cfg->pgb / ((double)e->cfg->pgb + (double)e->cfg->pbg));
+                for (int k = 0; k < NN; ++k) {
+                    float u;
+                    if (e->cfg->rng_mode == CMO_RNG_TAPE) u = rc->tape->ge_init_u[(size_t)rc->b * NN + k];
+                    else { uint32_t x[4]; philox_at(rc, SITE_GE_INIT, (uint32_t)k >> 2, x); u = u32_to_unit_f32(x[k & 3]); }
+                    cur[k] = (u >= bad_rate) ? 1 : 0;
+                }
+            } else memset(cur, init_mode == 1 ? 0 : 1, (size_t)NN);
+            for (int k = 0; k < NN; ++k) ch[k] = (float)cur[k];
             l0 = 1;
+            if (per_step) l1 = 1;                                       /* no transition at reset */
         } else {
             memcpy(cur, e->ge_state, (size_t)NN);
         }
-        for (int l = l0; l < L; ++l) {
+        for (int l = l0; l < l1; ++l) {
             for (int k = 0; k < NN; ++k) {
                 ugb[k] = draw_link_uniform(rc, 1, slot, (l * 2 + 0) * NN + k);
                 ubg[k] = draw_link_uniform(rc, 1, slot, (l * 2 + 1) * NN + k);
@@ -268,6 +282,8 @@ static void comm_channels(env_view *e, rng_ctx *rc, int slot, float *ch) {
             memcpy(cur, nxt, (size_t)NN);
             for (int k = 0; k < NN; ++k) ch[l * NN + k] = (float)cur[k];
         }
+        if (per_step)                                                   /* .expand(GCNHops, ...): every hop sees the same state */
+            for (int l = 1; l < L; ++l) for (int k = 0; k < NN; ++k) ch[l * NN + k] = (float)cur[k];
         memcpy(e->ge_state, cur, (size_t)NN);
         break;
     }

@@ -121,7 +121,8 @@ def cfg_json(scenario, p, channel, max_path_length):
              capture_reward=float(abs(p['capture_reward'])), step_cost=float(p['step_cost']),
              rm=float(p['rm']), penalty=float(p['penalty']),
              lazy_penalty=float(p.get('lazy_penalty', 0)), revisit_penalty=float(p.get('revisit_penalty', 0)),
-             obst=p.get('obstComplex', 'Easy'), add_clock=int(p.get('add_clock', 0)))
+             obst=p.get('obstComplex', 'Easy'), add_clock=int(p.get('add_clock', 0)),
+             ge_init=int(p.get('GE_INIT', 1)), loss_apply=int(p.get('loss_apply', 1)))
     return json.dumps(c)
 
 
@@ -228,6 +229,7 @@ def split_tape(tape, scenario, env, L, reset_happened, channel):
     # torch.rand draws: IID -> one [L,n,n] per comm update; GE -> 2 per hop transition.
     iid = np.zeros((2, L, n, n), dtype=np.float32)
     ge = np.zeros((2, L, 2, n, n), dtype=np.float32)
+    ge_init = np.zeros((n, n), dtype=np.float32)
     r = [t.numpy() for t in tape.rands]
     if channel == 'IID':
         if tape.first_call:            # initial reset: only the reset's comm update draws
@@ -239,15 +241,21 @@ def split_tape(tape, scenario, env, L, reset_happened, channel):
             if reset_happened:
                 iid[1] = r[1]
     elif channel == 'GE':
-        # step update: L transitions (2 rands each); reset update (GE_INIT=1, loss_apply=1): L-1 transitions
+        # step update: L transitions (2 rands each) with loss_apply=1, ONE with loss_apply=0; reset update: [one (n,n)
+        # rand of get_init_state when GE_INIT is neither 0 nor 1] then L-1 transitions (loss_apply=1) or none
+        per_step = getattr(env, 'loss_apply', 1) == 0
+        rand_init = getattr(env, 'GE_INIT', 1) not in (0, 1)
         k = 0
         if not tape.first_call:
-            for l in range(L):
+            for l in range(1 if per_step else L):
                 ge[0, l, 0], ge[0, l, 1] = r[k], r[k + 1]
                 k += 2
         if reset_happened or tape.first_call:
             slot = 1
-            for l in range(1, L):
+            if rand_init:
+                ge_init[:] = r[k]
+                k += 1
+            for l in range(1, 1 if per_step else L):
                 ge[slot, l, 0], ge[slot, l, 1] = r[k], r[k + 1]
                 k += 2
         assert k == len(r), (k, len(r))
@@ -255,6 +263,7 @@ def split_tape(tape, scenario, env, L, reset_happened, channel):
         assert len(r) == 0
     out['iid_u'] = iid
     out['ge_u'] = ge
+    out['ge_init_u'] = ge_init
     return out
 
 
@@ -280,12 +289,13 @@ def record_env(ns, scenario, params, B, T, seed, channel='FC', max_path_length=N
         if channel == 'GE':   # GE is unreachable from params (App. B-4): switch it on directly
             e.channelType = 'GE'
             e.Pgb, e.Pbg, e.GE_INIT = params['Pgb'], params['Pbg'], params['GE_INIT']
+            e.loss_apply = params['loss_apply']
         if scenario == 'pp':
             hook_prey_index(e, tape)
         envs.append(e)
         vecs.append(VecEnvExecutor(envs=[e], max_path_length=mpl))
 
-    rec = {k: [] for k in ('actions', 'prey_tape', 'spawn_tape', 'spawn_n', 'iid_u', 'ge_u', 'reward', 'done',
+    rec = {k: [] for k in ('actions', 'prey_tape', 'spawn_tape', 'spawn_n', 'iid_u', 'ge_u', 'ge_init_u', 'reward', 'done',
                            'details', 'obs', 'agent_pos', 'prey_pos', 'prey_alive', 'prey_alive_info', 'visited',
                            'total_capture', 'step_count', 'success', 'dist_adj', 'channels')}
 
@@ -328,7 +338,7 @@ def record_env(ns, scenario, params, B, T, seed, channel='FC', max_path_length=N
                 if scenario == 'pp':
                     pinfo.append(np.asarray(info['prey_alive'][0], dtype=np.uint8))
             rec['actions'].append(np.stack(acts))
-            for k in ('prey_tape', 'spawn_tape', 'spawn_n', 'iid_u', 'ge_u'):
+            for k in ('prey_tape', 'spawn_tape', 'spawn_n', 'iid_u', 'ge_u', 'ge_init_u'):
                 rec[k].append(np.stack([d[k] for d in tapes]))
             rec['reward'].append(np.array(rew))
             rec['done'].append(np.array(dn))
@@ -344,6 +354,8 @@ def record_env(ns, scenario, params, B, T, seed, channel='FC', max_path_length=N
         out.pop('iid_u', None)
     if channel != 'GE':
         out.pop('ge_u', None)
+    if channel != 'GE' or params.get('GE_INIT', 1) in (0, 1):
+        out.pop('ge_init_u', None)
     if scenario != 'pp':
         out.pop('prey_tape', None)
     for k, v in init_tape.items():
@@ -720,6 +732,18 @@ def main():
     # GE channel through the env (direct switch-on) on CO map20
     fx['co_map20_ge'] = record_env(ns, 'co', co_params(20, 2, 0.06, max_env_steps=10), B=2, T=14, seed=9,
                                    channel='GE', p_random=1.0)
+    # GE variants that exist in the code but not on the CLI: one transition per env step
+    # (loss_apply=0), all-bad and random (stationary) initial states
+    fx['co_map20_ge_step'] = record_env(ns, 'co', dict(co_params(20, 2, 0.06, max_env_steps=7), loss_apply=0), B=2, T=12,
+                                        seed=12, channel='GE', p_random=1.0)
+    fx['co_map20_ge_bad'] = record_env(ns, 'co', dict(co_params(20, 2, 0.06, max_env_steps=7), GE_INIT=0), B=2, T=12,
+                                       seed=13, channel='GE', p_random=1.0)
+    fx['pp_map10_ge_bad_step'] = record_env(ns, 'pp', dict(pp_params(10, 1, 0.04, 2, max_env_steps=9), GE_INIT=0,
+                                                           loss_apply=0), B=3, T=25, seed=14, channel='GE')
+    # (random init together with loss_apply=0 is shape-inconsistent in the reference itself - the state gets an extra
+    # leading axis, env_communication.py:121 - so that combination has no fixture and is refused by cm_env_create)
+    fx['pp_map10_ge_rand'] = record_env(ns, 'pp', dict(pp_params(10, 1, 0.04, 2, max_env_steps=9), GE_INIT=2), B=3, T=25,
+                                        seed=15, channel='GE')
     # Hard obstacles
     fx['co_map10_hard'] = record_env(ns, 'co', co_params(10, 1, 0.06, max_env_steps=40, obst='Hard'), B=2, T=45,
                                      seed=10, p_random=1.0)

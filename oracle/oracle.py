@@ -34,7 +34,7 @@ class Cfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "scenario", "n_envs", "n_agents", "n_preys", "grid", "rsen", "load", "max_steps", "max_path_length",
         "n_hops", "rcom", "channel", "obst_hard", "add_clock", "rng_mode", "env_id_offset")] + [
-        ("ploss", C.c_float), ("pgb", C.c_float), ("pbg", C.c_float), ("_pad", C.c_float)] + [
+        ("ploss", C.c_float), ("pgb", C.c_float), ("pbg", C.c_float), ("ge_flags", C.c_int32)] + [
         (n, C.c_double) for n in ("capture_reward", "step_cost", "move_cost", "penalty", "lazy_penalty",
                                   "revisit_penalty", "final_reward")] + [("seed", C.c_uint64)]
 
@@ -47,7 +47,7 @@ class State(C.Structure):
 
 class Tape(C.Structure):
     _fields_ = [("prey", C.c_void_p), ("spawn", C.c_void_p), ("spawn_cap", C.c_int32), ("_pad", C.c_int32),
-                ("iid_u", C.c_void_p), ("ge_u", C.c_void_p)]
+                ("iid_u", C.c_void_p), ("ge_u", C.c_void_p), ("ge_init_u", C.c_void_p)]
 
 
 class Out(C.Structure):
@@ -107,7 +107,7 @@ def _p(a):
 def make_cfg(scenario, n_envs, n_agents, grid, rsen, n_preys=0, load=2, max_steps=200, max_path_length=None,
              n_hops=2, rcom=9, channel="FC", ploss=0.0, pgb=0.0196, pbg=0.282, obst="Easy", add_clock=0,
              capture_reward=None, step_cost=None, rm=0.0, penalty=None, lazy_penalty=1.0, revisit_penalty=0.5,
-             final_reward=100.0, seed=1, env_id_offset=0, rng_mode=RNG_PHILOX):
+             final_reward=100.0, seed=1, env_id_offset=0, rng_mode=RNG_PHILOX, ge_init=1, loss_apply=1):
     """Signs follow the env constructors: costs are stored as -abs(x) (predator_prey.py:65-68,
     coverage.py:86-92).  Defaults are exp_runners/*/utils_{pp,co}.py."""
     sc = PP if scenario in ("pp", PP) else CO
@@ -123,6 +123,8 @@ def make_cfg(scenario, n_envs, n_agents, grid, rsen, n_preys=0, load=2, max_step
     c.n_hops, c.rcom, c.channel = n_hops, rcom, CH[channel]
     c.obst_hard, c.add_clock, c.rng_mode, c.env_id_offset = int(obst == "Hard"), add_clock, rng_mode, env_id_offset
     c.ploss, c.pgb, c.pbg = ploss, pgb, pbg
+    # GE_INIT 1 good / 0 bad / anything else random (env_communication.py:54-60); loss_apply 0 = per env step (:21)
+    c.ge_flags = (0 if loss_apply else 1) | ((0 if ge_init == 1 else (1 if ge_init == 0 else 2)) << 1)
     c.capture_reward, c.step_cost, c.move_cost = abs(capture_reward), -abs(step_cost), -abs(rm)
     c.penalty, c.lazy_penalty, c.revisit_penalty = -abs(penalty), -abs(lazy_penalty), -abs(revisit_penalty)
     c.final_reward, c.seed = final_reward, seed
@@ -136,7 +138,8 @@ def cfg_from_json(js, n_envs, rng_mode=RNG_TAPE, seed=1):
                     rcom=j["rcom"], channel=j["channel"], ploss=j["ploss"], pgb=j["pgb"], pbg=j["pbg"],
                     obst=j["obst"], add_clock=j["add_clock"], capture_reward=j["capture_reward"],
                     step_cost=j["step_cost"], rm=j["rm"], penalty=j["penalty"], lazy_penalty=j["lazy_penalty"],
-                    revisit_penalty=j["revisit_penalty"], seed=seed, rng_mode=rng_mode)
+                    revisit_penalty=j["revisit_penalty"], seed=seed, rng_mode=rng_mode,
+                    ge_init=j.get("ge_init", 1), loss_apply=j.get("loss_apply", 1))
 
 
 class OracleEnv:
@@ -172,10 +175,10 @@ class OracleEnv:
         self._out = Out(*[_p(a) for a in (self.obs, self.reward, self.done, self.details, self.dist_adj,
                                           self.channels, self.prey_alive_info)])
 
-    def _tape(self, prey=None, spawn=None, iid_u=None, ge_u=None):
-        self._keep = [np.ascontiguousarray(a) if a is not None else None for a in (prey, spawn, iid_u, ge_u)]
-        prey, spawn, iid_u, ge_u = self._keep
-        return Tape(_p(prey), _p(spawn), 0 if spawn is None else spawn.shape[1], 0, _p(iid_u), _p(ge_u))
+    def _tape(self, prey=None, spawn=None, iid_u=None, ge_u=None, ge_init_u=None):
+        self._keep = [np.ascontiguousarray(a) if a is not None else None for a in (prey, spawn, iid_u, ge_u, ge_init_u)]
+        prey, spawn, iid_u, ge_u, ge_init_u = self._keep
+        return Tape(_p(prey), _p(spawn), 0 if spawn is None else spawn.shape[1], 0, _p(iid_u), _p(ge_u), _p(ge_init_u))
 
     def reset(self, **tape):
         t = self._tape(**tape)

@@ -16,7 +16,8 @@ def params_from_cfg(cfg):
              Rsen=cfg.rsen, n_agents=cfg.n_agents, n_preys=cfg.n_preys, n_gcn_layers=cfg.n_hops, mode="train",
              trRcom=cfg.rcom, trpl=cfg.ploss, Pgb=cfg.pgb, Pbg=cfg.pbg, lazy_penalty=abs(cfg.lazy_penalty),
              revisit_penalty=abs(cfg.revisit_penalty), obstComplex="Hard" if cfg.obst_hard else "Easy",
-             add_clock=cfg.add_clock)
+             add_clock=cfg.add_clock, loss_apply=0 if (cfg.ge_flags & 1) else 1,
+             GE_INIT={0: 1, 1: 0, 2: 2}[(cfg.ge_flags >> 1) & 3])
     return ("pp" if pp else "co"), p, ch
 
 

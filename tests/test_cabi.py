@@ -32,7 +32,7 @@ def test_struct_layouts_match_header_sizes():
     import ctypes as C
     from com_marl_amd import _lib
     assert C.sizeof(_lib.EnvCfg) == 16 * 4 + 4 * 4 + 7 * 8 + 8
-    assert C.sizeof(_lib.RngTape) == 5 * 8
+    assert C.sizeof(_lib.RngTape) == 6 * 8
     assert C.sizeof(_lib.StepOut) == 10 * 8
     assert C.sizeof(_lib.EnvState) == 9 * 8
     assert C.sizeof(_lib.PolicyWeights) == 10 * 4 + 16 * 8

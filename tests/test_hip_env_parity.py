@@ -100,6 +100,20 @@ def test_philox_co_map30_ge(hip):
     assert n >= 64
 
 
+@pytest.mark.parametrize("ge_init,loss_apply", [(1, 0), (0, 1), (0, 0), (2, 1)])
+def test_philox_ge_variants(ge_init, loss_apply, hip):
+    """GE_INIT good / bad / random x loss per hop / per env step on the production Philox stream."""
+    n = _lockstep(dict(scenario="pp", n_envs=96, n_agents=5, n_preys=3, grid=10, rsen=1, max_steps=9, max_path_length=9,
+                       channel="GE", ge_init=ge_init, loss_apply=loss_apply, pgb=0.2, pbg=0.3), steps=25, hip=hip)
+    assert n >= 96
+
+
+def test_ge_random_init_with_per_step_loss_is_refused(hip):
+    from com_marl_amd import _lib as L
+    with pytest.raises(L.CommarlError, match="shape-inconsistent"):
+        hip.HipEnv(O.make_cfg("pp", 4, 4, 10, 1, n_preys=4, channel="GE", ge_init=2, loss_apply=0))
+
+
 def test_philox_pp_load3_and_fl(hip):
     _lockstep(dict(scenario="pp", n_envs=512, n_agents=8, n_preys=8, grid=10, rsen=1, load=3, max_steps=30,
                    channel="FL", ploss=1.0), steps=70, hip=hip, check_every=7)

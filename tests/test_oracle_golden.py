@@ -28,7 +28,7 @@ def replay(path, make_env, check_every=1):
             if k not in z.files:
                 return None
             return z[k] if t is None else z[k][t]
-        return dict(prey=g("prey_tape"), spawn=g("spawn_tape"), iid_u=g("iid_u"), ge_u=g("ge_u"))
+        return dict(prey=g("prey_tape"), spawn=g("spawn_tape"), iid_u=g("iid_u"), ge_u=g("ge_u"), ge_init_u=g("ge_init_u"))
 
     def check_state(t, where):
         np.testing.assert_array_equal(env.agent_pos, z["agent_pos"][t], err_msg=f"agent_pos {where}")
