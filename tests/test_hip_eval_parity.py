@@ -33,14 +33,14 @@ def _setup(torch, scenario, B, mpl, seed=7):
     return env, pol, params
 
 
-def _oracle_greedy_episodes(env, pol, scenario, B, T, seed, mpl):
+def _oracle_greedy_episodes(env, pol, scenario, B, T, seed, mpl, rcom=9, channel=None):
     """The reference eval loop (eval_pp.py:25-91) on the oracle, one env at a time semantics:
     argmax of the policy probabilities, stop at the first done."""
     N = env.n_agents
-    ch = "IID" if scenario == "co" else "FC"
+    ch = channel or ("IID" if scenario == "co" else "FC")
     cfg = O.make_cfg(scenario, B, N, env.maps, env.Rsen, n_preys=env.n_preys, load=2,
                      max_steps=mpl if scenario == "pp" else 400, max_path_length=mpl, channel=ch, ploss=env.pl,
-                     seed=seed, rng_mode=O.RNG_PHILOX)
+                     seed=seed, rng_mode=O.RNG_PHILOX, rcom=rcom)
     oe = O.OracleEnv(cfg)
     sd = {k: v.detach().cpu().numpy() for k, v in pol.state_dict().items()}
     oe.reset()
@@ -103,6 +103,31 @@ def test_eval_model_greedy_matches_oracle(scenario, torch_cuda):
     st = env.batch.get_state()
     assert (st["rng_step"] > r0).all() and len(data2) == 3
     assert (st["agent_pos"] != pos0).any()
+
+
+def test_transfer_scale_eval_small_team_weights_on_a_larger_map(torch_cuda):
+    """SURVEY §8f-4 (train small -> test large): the weights do not depend on the team size, so a state_dict of a
+    4-agent policy evaluates on a 9-agent map-20 env built with mode='test' (te* communication parameters: range
+    adjacency teRcom, IID loss tepl) - greedy episodes identical to the oracle's."""
+    torch = torch_cuda
+    from com_marl_amd import envs as E, nets
+    from com_marl_amd.evaluate import eval_model
+    mpl, B, seed = 25, 12, 4
+    small = _setup(torch, "pp", 4, mpl, seed=seed)[1]                     # "trained" on map 10, N = 4
+    params = dict(load=2, max_env_steps=mpl, capture_reward=10, step_cost=0.1, rm=0, penalty=0, grid_size=20, Rsen=1,
+                  n_agents=9, n_preys=7, n_gcn_layers=2, mode="test", trRcom=9, trpl=0, teRcom=5, tepl=0.25, seed=seed)
+    env = E.PredatorPreyWrapper(centralized=True, params=params, n_envs=B, device="cuda:0")
+    assert env.channelType == "IID" and env.pl == 0.25 and env.Rcom == 5 and not env.batch.adj_const
+    big = nets.CommCategoricalMLPPolicy(env.spec, n_agents=9, device="cuda:0")
+    big.load_state_dict(small.state_dict())                               # same names, same shapes: d = 21 either way
+    data, epi_success, epi_rewards, _ = eval_model(env, big, 0, n_eval_episodes=B, max_env_steps=mpl)
+    rewards, details, success, degs, min_gap = _oracle_greedy_episodes(env, big, "pp", B, mpl, seed, mpl, rcom=5,
+                                                                       channel="IID")
+    assert min_gap > 1e-5
+    for b in range(B):
+        np.testing.assert_array_equal(data[b][1]["reward"], rewards[b])
+        np.testing.assert_array_equal(data[b][0], success[b])
+        np.testing.assert_allclose(data[b][1]["nodeDeg"], degs[b], rtol=1e-6)
 
 
 def test_eval_refuses_render_and_honours_flag(torch_cuda):
