@@ -76,3 +76,9 @@ def test_no_gpu_means_loud_failure():
     with pytest.raises(CommarlError):
         envs.GridEnvBatch("pp", dict(n_agents=4, n_preys=4, grid_size=10, Rsen=1, n_gcn_layers=2, trpl=0,
                                      max_env_steps=200), 2, device="cpu")
+
+
+def test_graft_entry_build_runs():
+    """The driver's build check: compiles (no-op when up to date), imports the package, resolves every symbol."""
+    import __graft_entry__ as g
+    g.build()
