@@ -29,14 +29,14 @@
 namespace cm {
 namespace mf {
 
-template <int HEAD, int KPAD, int MAXMK>
-__global__ __launch_bounds__(TPB) void fwd_mfma_kernel(FwdArgs a, TrunkW tw, PolHead ph, CritHead chd) {
+template <int HEAD, int KPAD, int MAXMK, int NW>
+__global__ __launch_bounds__(64 * NW) void fwd_mfma_kernel(FwdArgs a, TrunkW tw, PolHead ph, CritHead chd) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    fwd_body<HEAD, KPAD, MAXMK>(a, tw, ph, chd, lds, blockIdx.x, nullptr);
+    fwd_body<HEAD, KPAD, MAXMK, NW>(a, tw, ph, chd, lds, blockIdx.x, nullptr);
 }
 
 
-template <int HEAD, int KPAD, int MAXMK>
+template <int HEAD, int KPAD, int MAXMK, int NW = 4>
 static int launch(FwdArgs a, const TrunkW &tw, const PolHead &ph, const CritHead &chd, void *stream) {
     a.EPB = pick_epb(a.N);
     const int rows_cap = (a.EPB * a.N + 15) & ~15;
@@ -44,7 +44,7 @@ static int launch(FwdArgs a, const TrunkW &tw, const PolHead &ph, const CritHead
     if (lds > 160 * 1024) return set_error(CM_ERR_ARG, "policy forward: n_agents too large for the 160 KB LDS tile");
     static bool attr_set = false;
     if (!attr_set) {
-        CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fwd_mfma_kernel<HEAD, KPAD, MAXMK>),
+        CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fwd_mfma_kernel<HEAD, KPAD, MAXMK, NW>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
@@ -57,7 +57,7 @@ static int launch(FwdArgs a, const TrunkW &tw, const PolHead &ph, const CritHead
         CM_HIP(hipMemset(dbuf, 0, nb));
         a.probe = dbuf;
         for (int rep = 0; rep < 3; ++rep)
-            hipLaunchKernelGGL((fwd_mfma_kernel<HEAD, KPAD, MAXMK>), dim3(blocks), dim3(TPB), lds, (hipStream_t)stream, a, tw, ph, chd);
+            hipLaunchKernelGGL((fwd_mfma_kernel<HEAD, KPAD, MAXMK, NW>), dim3(blocks), dim3(64 * NW), lds, (hipStream_t)stream, a, tw, ph, chd);
         CM_HIP(hipDeviceSynchronize());
         std::vector<unsigned long long> h((size_t)blocks * NPROBE);
         CM_HIP(hipMemcpy(h.data(), dbuf, nb, hipMemcpyDeviceToHost));
@@ -79,7 +79,7 @@ static int launch(FwdArgs a, const TrunkW &tw, const PolHead &ph, const CritHead
         a.probe = nullptr;
         return CM_OK;
     }
-    hipLaunchKernelGGL((fwd_mfma_kernel<HEAD, KPAD, MAXMK>), dim3(blocks), dim3(TPB), lds, (hipStream_t)stream, a, tw, ph, chd);
+    hipLaunchKernelGGL((fwd_mfma_kernel<HEAD, KPAD, MAXMK, NW>), dim3(blocks), dim3(64 * NW), lds, (hipStream_t)stream, a, tw, ph, chd);
     CM_HIP(hipGetLastError());
     return CM_OK;
 }
@@ -96,8 +96,13 @@ static int dispatch(const FwdArgs &a, const TrunkW &tw, const PolHead &ph, const
     const int mk = a.N < mk_min ? 0 : (a.N <= 80 ? 25 : 64);    // (row blocks) x (column blocks) of 16
     (void)nn;
     const bool quad = a.N == 4 && pick_epb(4) * 4 <= 32;    // teams of 4: the register-resident attention / aggregation kernel
+    // large teams run 8-wave workgroups (one workgroup per CU fits in LDS: two waves per SIMD hide each other's
+    // latencies); COMMARL_FWD_WAVES=4 selects the 4-wave build of the same code for A/B timing
+    static const bool w8_on = [] { const char *e = getenv("COMMARL_FWD_WAVES"); return !(e && e[0] == '4'); }();
+    const bool w8 = w8_on && a.N >= 32;   // measured: N = 54 245 -> 178 us, N = 72 280 -> 213 us; N = 24 (48 rows) is faster on 4 waves
 #define CM_FWD(K) (quad ? launch<HEAD, K, -1>(a, tw, ph, chd, stream) : mk == 0 ? launch<HEAD, K, 0>(a, tw, ph, chd, stream) \
-                   : mk == 25 ? launch<HEAD, K, 25>(a, tw, ph, chd, stream) : launch<HEAD, K, 64>(a, tw, ph, chd, stream))
+                   : mk == 25 ? (w8 ? launch<HEAD, K, 15, 8>(a, tw, ph, chd, stream) : launch<HEAD, K, 25>(a, tw, ph, chd, stream)) \
+                              : (w8 ? launch<HEAD, K, 32, 8>(a, tw, ph, chd, stream) : launch<HEAD, K, 64>(a, tw, ph, chd, stream)))
     switch (kpad) {      // obs dims of the reference scenarios: PP sen1 21, CO sen1 29, PP sen2 53, CO sen2 77 (+clock 78)
     case 32: return CM_FWD(32);
     case 64: return CM_FWD(64);

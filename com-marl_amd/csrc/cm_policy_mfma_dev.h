@@ -60,10 +60,10 @@ constexpr int NPROBE = 16;
 // k < kreal <= KPAD.  load() pulls this wave's B fragments (weights) into registers - it is issued one
 // layer AHEAD of run() so the L2 latency hides under the previous layer's MFMAs; run() streams the A
 // operand from LDS.
-template <int KPAD, int OUT>
+template <int KPAD, int OUT, int NW = 4>
 struct Layer {
     static constexpr int CT = OUT / 16;                // column tiles of the layer
-    static constexpr int NCT = CT >= 4 ? CT / 4 : 1;   // column tiles per wave
+    static constexpr int NCT = CT >= NW ? CT / NW : 1; // column tiles per wave (NW waves per workgroup)
     static constexpr int KS = KPAD / 4;                // k-steps
     float b[NCT][KS];
     float bv[NCT];
@@ -76,7 +76,7 @@ struct Layer {
     static constexpr int PACK_FLOATS = CT * (KS / 4) * 64 * 4;
     __device__ __forceinline__ void load(const float *__restrict__ P, const float *__restrict__ bias, int wave, int lane,
                                          int out_real = OUT) {
-        const int ct0 = CT >= 4 ? wave * NCT : (wave % CT);
+        const int ct0 = CT >= NW ? wave * NCT : (wave % CT);
         const float4 *p4 = reinterpret_cast<const float4 *>(P);
 #pragma unroll
         for (int t = 0; t < NCT; ++t) {
@@ -97,9 +97,9 @@ struct Layer {
     template <bool TANH>
     __device__ __forceinline__ void run(const float *in, int in_stride, float *out, int out_stride, int row_tiles,
                                         int wave, int lane) const {
-        const int ct0 = CT >= 4 ? wave * NCT : (wave % CT);
-        const int rt_start = CT >= 4 ? 0 : wave / CT;
-        const int rt_step = CT >= 4 ? 1 : 4 / CT;
+        const int ct0 = CT >= NW ? wave * NCT : (wave % CT);
+        const int rt_start = CT >= NW ? 0 : wave / CT;
+        const int rt_step = CT >= NW ? 1 : NW / CT;
         const int c = lane & 15, g = lane >> 4;
         for (int rt = rt_start; rt < row_tiles; rt += 2 * rt_step) {
             const int rtB = rt + rt_step;
@@ -175,9 +175,10 @@ __device__ __forceinline__ float row16_sum(float v) {
 // teams where an N x N tile would be mostly padding: N < 32).
 // scores[e][i][j] = sum_k Q[e*N+i][k] * K[e*N+j][k]   (K = 64): 16x16 output tiles dealt round-robin to waves;
 // both operands are 16-byte LDS reads of one activation row.
-__device__ __forceinline__ void scores_mfma(const float *Q, const float *K, float *M, int N, int NP, int envs, int wave, int lane) {
+__device__ __forceinline__ void scores_mfma(const float *Q, const float *K, float *M, int N, int NP, int envs, int wave, int lane,
+                                            int nw = 4) {
     const int c = lane & 15, g = lane >> 4, NT = (N + 15) >> 4, per_env = NT * NT;
-    for (int t = wave; t < envs * per_env; t += 4) {
+    for (int t = wave; t < envs * per_env; t += nw) {
         const int e = t / per_env, rc = t - e * per_env, rt = rc / NT, ct = rc - rt * NT;
         const int ra = min(rt * 16 + c, N - 1), rb = min(ct * 16 + c, N - 1);          // clamped rows: results masked below
         const float4 *pa = reinterpret_cast<const float4 *>(Q + (size_t)(e * N + ra) * SE + 4 * g);
@@ -207,9 +208,10 @@ __device__ __forceinline__ void scores_mfma(const float *Q, const float *K, floa
 // and reused by every row tile; A rows are 16-byte reads of the zero-padded [rows][NPA] tile.
 template <int MAXKS>
 __device__ __forceinline__ void agg_mfma(const float *A, int NPA, const float *HW, const float *bias, const float *Eres,
-                                         float *Hout, int N, int envs, int wave, int lane) {
+                                         float *Hout, int N, int envs, int wave, int lane, int nw = 4) {
     const int c = lane & 15, g = lane >> 4, NT = (N + 15) >> 4, KQ = NT;            // k-steps of 16
-    const int col = wave * 16 + c;
+    const int col = (wave & 3) * 16 + c;              // 4 column tiles; with 8 waves two waves share one and split the row tiles
+    const int rt0 = 2 * (wave >> 2), rt_stride = 2 * (nw >> 2);
     const float bv = bias ? bias[col] : 0.0f;
     for (int e = 0; e < envs; ++e) {
         float b[MAXKS];
@@ -218,7 +220,7 @@ __device__ __forceinline__ void agg_mfma(const float *A, int NPA, const float *H
             const int k = 16 * (kk >> 2) + 4 * g + (kk & 3);
             b[kk] = (kk < 4 * KQ && k < N) ? HW[(size_t)(e * N + k) * SE + col] : 0.0f;
         }
-        for (int rt = 0; rt < NT; rt += 2) {            // two row tiles in flight: independent accumulator chains
+        for (int rt = rt0; rt < NT; rt += rt_stride) {   // two row tiles in flight: independent accumulator chains
             const bool hasB = rt + 1 < NT;
             const int ra = min(rt * 16 + c, N - 1), rb = min((hasB ? rt + 1 : rt) * 16 + c, N - 1);
             const float4 *pa = reinterpret_cast<const float4 *>(A + (size_t)(e * N + ra) * NPA + 4 * g);
@@ -290,11 +292,13 @@ __host__ __device__ inline size_t lds_floats(int rows_pad, int epb, int N) {
 
 // HEAD 0 = policy, 1 = critic; KPAD = obs dim rounded up to 16; MAXMK = mask elements per thread held in
 // registers across a hop's MFMAs (0 for small teams: N*N <= MAXMK*256)
-template <int HEAD, int KPAD, int MAXMK>
+template <int HEAD, int KPAD, int MAXMK, int NW = 4>
 // `lds` = the workgroup's dynamic LDS block, `blk` = workgroup index (envs blk*EPB ..), `act_lds` = optional [rows] LDS
 // array that also receives the sampled actions (fused rollout kernel: the env step of the same envs reads them there)
 __device__ __forceinline__ void fwd_body(const FwdArgs &a, const TrunkW &tw, const PolHead &ph, const CritHead &chd, float *lds,
                                          int blk, int32_t *act_lds) {
+    constexpr int TPBW = 64 * NW, NG = 4 * NW;      // threads and 16-lane groups per workgroup (NW = 4 or 8 waves)
+    static_assert(NW == 4 || (NW == 8 && MAXMK > 0), "8-wave workgroups are built for the large-team path only");
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int N = a.N, d = a.d, L = a.L, NN = N * N, NP = N | 1;
     const int s0 = blk * a.EPB;
@@ -322,18 +326,18 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &a, const TrunkW &tw, con
     constexpr int OBSR = 8;
     const float *src = a.obs + (size_t)s0 * N * d;
     const int obs_total = RT * 16 * KPAD;
-    const bool obs_pre = obs_total <= OBSR * TPB;
+    const bool obs_pre = obs_total <= OBSR * TPBW;
     float ox[OBSR];
     if (obs_pre) {
 #pragma unroll
         for (int qq = 0; qq < OBSR; ++qq) {
-            const int k = tid + qq * TPB, r = k / KPAD, f = k - r * KPAD;
+            const int k = tid + qq * TPBW, r = k / KPAD, f = k - r * KPAD;
             ox[qq] = (k < obs_total && r < rows && f < d) ? src[(size_t)r * d + f] : 0.0f;
         }
     }
-    Layer<KPAD, EH> l_enc1;
+    Layer<KPAD, EH, NW> l_enc1;
     l_enc1.load(tw.enc1_p, tw.enc_b1, wave, lane);
-    Layer<EH, EMB> l_enc2;
+    Layer<EH, EMB, NW> l_enc2;
     l_enc2.load(tw.enc2_p, tw.enc_b2, wave, lane);
     const uint32_t draw_step = a.policy_step + (a.step_base ? *a.step_base : 0u);
     float gbias[4];                                     // quad path: GCN biases of hops 0/1 for this wave's two column tiles
@@ -344,30 +348,30 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &a, const TrunkW &tw, con
     if (obs_pre) {
 #pragma unroll
         for (int qq = 0; qq < OBSR; ++qq) {
-            const int k = tid + qq * TPB, r = k / KPAD, f = k - r * KPAD;
+            const int k = tid + qq * TPBW, r = k / KPAD, f = k - r * KPAD;
             if (k < obs_total) X[(size_t)r * SX + f] = ox[qq];
         }
     } else {
-        for (int k = tid; k < obs_total; k += TPB) {
+        for (int k = tid; k < obs_total; k += TPBW) {
             const int r = k / KPAD, f = k - r * KPAD;
             X[(size_t)r * SX + f] = (r < rows && f < d) ? src[(size_t)r * d + f] : 0.0f;
         }
     }
-    Layer<EMB, EMB> l_sq;                               // 64x64 square layers: attention, then the GCN hops
+    Layer<EMB, EMB, NW> l_sq;                               // 64x64 square layers: attention, then the GCN hops
     l_sq.load(tw.attn_p, nullptr, wave, lane);
     lds_barrier();
     if (a.stop == 1) return;
     CM_PROBE(1);
     l_enc1.template run<true>(X, SX, bufA, SA, RT, wave, lane);
-    Layer<EMB, EMB> l_g;                                // quad path: GCN weights, one hop ahead
+    Layer<EMB, EMB, NW> l_g;                                // quad path: GCN weights, one hop ahead
     if (quad_path && L > 0) l_g.load(tw.gcn_p, nullptr, wave, lane);
     lds_barrier();
     if (a.stop == 2) return;
     CM_PROBE(2);
     l_enc2.template run<true>(bufA, SA, E, SE, RT, wave, lane);
-    Layer<EMB, HEAD == 0 ? H1 : DH> l_x1;               // first head layer (policy 64 -> 128, critic 64 -> 64)
+    Layer<EMB, HEAD == 0 ? H1 : DH, NW> l_x1;               // first head layer (policy 64 -> 128, critic 64 -> 64)
     if (EARLY) l_x1.load(HEAD == 0 ? ph.h1_p : chd.d1_p, HEAD == 0 ? ph.b1 : chd.b1, wave, lane);
-    Layer<H1, H2> l_h2;
+    Layer<H1, H2, NW> l_h2;
     lds_barrier();
     if (a.stop == 3) return;
     CM_PROBE(3);
@@ -477,10 +481,10 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &a, const TrunkW &tw, con
     // ---- attention scores + softmax: N x N per env ----
     const bool big = MAXMK > 0;                         // matrix-core path for the N x N products (N >= 16)
     if (big) {
-        scores_mfma(T, E, M, N, NP, envs, wave, lane);
+        scores_mfma(T, E, M, N, NP, envs, wave, lane, NW);
         lds_barrier();
         if (a.stop == 41) return;
-        for (int r0 = 0; r0 < rows; r0 += TPB / 16) {   // 16 lanes per matrix row, DPP row reductions
+        for (int r0 = 0; r0 < rows; r0 += NG) {   // 16 lanes per matrix row, DPP row reductions
             const int r = min(r0 + (tid >> 4), rows - 1), sl = tid & 15;
             float *m = M + (size_t)r * NP;
             float mx = -INFINITY;
@@ -493,7 +497,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &a, const TrunkW &tw, con
                 for (int j = sl; j < N; j += 16) m[j] = m[j] / sum;
         }
     } else {
-        for (int k = tid; k < envs * NN; k += TPB) {
+        for (int k = tid; k < envs * NN; k += TPBW) {
             const int e = k / NN, ij = k - e * NN, i = ij / N, j = ij - i * N;
             const float4 *q = reinterpret_cast<const float4 *>(T + (size_t)(e * N + i) * SE);
             const float4 *c = reinterpret_cast<const float4 *>(E + (size_t)(e * N + j) * SE);
@@ -506,7 +510,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &a, const TrunkW &tw, con
             M[(size_t)(e * N + i) * NP + j] = acc;
         }
         lds_barrier();
-        for (int r = tid; r < rows; r += TPB) {
+        for (int r = tid; r < rows; r += TPBW) {
             float *m = M + (size_t)r * NP;
             float mx = -INFINITY, sum = 0.0f;
             for (int j = 0; j < N; ++j) mx = fmaxf(mx, m[j]);
@@ -519,10 +523,10 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &a, const TrunkW &tw, con
     if (a.attn) {
         float *dst = a.attn + (size_t)s0 * NN;
         if (big) {                                      // 16 lanes per row: no per-element division
-            for (int r = tid >> 4; r < rows; r += TPB / 16)
+            for (int r = tid >> 4; r < rows; r += NG)
                 for (int j = tid & 15; j < N; j += 16) dst[(size_t)r * N + j] = M[(size_t)r * NP + j];
         } else {
-            for (int k = tid; k < envs * NN; k += TPB) { const int r = k / N, j = k - r * N; dst[k] = M[(size_t)r * NP + j]; }
+            for (int k = tid; k < envs * NN; k += TPBW) { const int r = k / N, j = k - r * N; dst[k] = M[(size_t)r * NP + j]; }
         }
     }
     if (a.stop == 5) return;
@@ -534,14 +538,14 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &a, const TrunkW &tw, con
         // latency hides under them; registers hold it until the A tile is written
         // 16-lane group gq = tid>>4 owns matrix rows gq, gq+16, ...; lane sl = tid&15 owns columns sl, sl+16, ...
         // mk[rb*JB + jb] is element (row rb*16+gq, column jb*16+sl): no divisions anywhere in the mask path
-        constexpr int JB = MAXMK == 25 ? 5 : 8;                             // column blocks per row (N <= 16*JB)
+        constexpr int JB = (MAXMK == 25 || MAXMK == 15) ? 5 : 8;            // column blocks per row (N <= 16*JB)
         float mk[MAXMK > 0 ? MAXMK : 1];
         const bool masked = a.adj || a.chan;
         if (MAXMK > 0 && masked) {
             const int gq = tid >> 4, sl = tid & 15;
 #pragma unroll
             for (int q = 0; q < MAXMK; ++q) {
-                const int r = (q / JB) * 16 + gq, j = (q % JB) * 16 + sl;
+                const int r = (q / JB) * NG + gq, j = (q % JB) * 16 + sl;
                 float v = 1.0f;
                 if (r < rows && j < N) {
                     const int e = envs == 1 ? 0 : r / N, i = r - e * N;
@@ -563,8 +567,8 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &a, const TrunkW &tw, con
                 const int gq = tid >> 4, sl = tid & 15;
 #pragma unroll
                 for (int rb = 0; rb < MAXMK / JB; ++rb) {
-                    const int r = rb * 16 + gq;
-                    if (rb * 16 < rows) {               // uniform: every group of the block shares rb
+                    const int r = rb * NG + gq;
+                    if (rb * NG < rows) {               // uniform: every group of the block shares rb
                         const bool live = r < rows;
                         const float *mr = M + (size_t)(live ? r : 0) * NP;
                         float v[JB];
@@ -587,13 +591,13 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &a, const TrunkW &tw, con
             lds_barrier();
             if (a.stop == 51 + l) return;
             agg_mfma<32>(Amat, NPA, T, tw.gcn_b ? tw.gcn_b + (size_t)l * EMB : nullptr,
-                         (l == L - 1 && !a.no_residual) ? E : nullptr, H, N, envs, wave, lane);
+                         (l == L - 1 && !a.no_residual) ? E : nullptr, H, N, envs, wave, lane, NW);
             lds_barrier();
             continue;
         }
         if (N <= 16) {
             // small teams: one thread builds its whole masked + renormalised row (no intermediate barrier)
-            for (int r = tid; r < rows; r += TPB) {
+            for (int r = tid; r < rows; r += TPBW) {
                 const int e = r / N, i = r - e * N;
                 const float *mr = M + (size_t)r * NP;
                 float *ar = Amat + (size_t)r * NP;
@@ -608,7 +612,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &a, const TrunkW &tw, con
                 for (int j = 0; j < N; ++j) ar[j] = ar[j] / den;
             }
         } else {
-            for (int k = tid; k < envs * NN; k += TPB) {    // A = M * Range * Chan_l (coalesced mask reads)
+            for (int k = tid; k < envs * NN; k += TPBW) {    // A = M * Range * Chan_l (coalesced mask reads)
                 const int e = k / NN, ij = k - e * NN, r = k / N, j = k - r * N;
                 float v = M[(size_t)r * NP + j];
                 if (a.adj) v *= a.adj[(size_t)(s0 + e) * NN + ij];
@@ -616,7 +620,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &a, const TrunkW &tw, con
                 Amat[(size_t)r * NP + j] = v;
             }
             lds_barrier();
-            for (int r = tid; r < rows; r += TPB) {
+            for (int r = tid; r < rows; r += TPBW) {
                 float *ar = Amat + (size_t)r * NP;
                 float sum = 0.0f;
                 for (int j = 0; j < N; ++j) sum += ar[j];
@@ -655,21 +659,21 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &a, const TrunkW &tw, con
     CM_PROBE(10);
     // ---- residual ----
     if (L == 0) {                                       // no hops: x = E (the hop epilogue adds the residual otherwise)
-        for (int k = tid; k < rows * EMB; k += TPB) { const int r = k >> 6, o = k & 63; H[(size_t)r * SE + o] = E[(size_t)r * SE + o]; }
+        for (int k = tid; k < rows * EMB; k += TPBW) { const int r = k >> 6, o = k & 63; H[(size_t)r * SE + o] = E[(size_t)r * SE + o]; }
         lds_barrier();
     }
 
     if (!EARLY) l_x1.load(HEAD == 0 ? ph.h1_p : chd.d1_p, HEAD == 0 ? ph.b1 : chd.b1, wave, lane);
     if (HEAD == 0) {
         if (!EARLY) l_h2.load(ph.h2_p, ph.b2, wave, lane);
-        Layer<H2, H3> l_h3;
+        Layer<H2, H3, NW> l_h3;
         l_h3.load(ph.h3_p, ph.b3, wave, lane);
         l_x1.template run<true>(H, SE, bufA, SA, RT, wave, lane);
         lds_barrier();
         CM_PROBE(11);
         l_h2.template run<true>(bufA, SA, T, SE, RT, wave, lane);
         const int A = ph.n_act;
-        Layer<H3, 16> l_h4;                              // 32 -> n_act (<= 8) logits, zero-padded to one column tile
+        Layer<H3, 16, NW> l_h4;                              // 32 -> n_act (<= 8) logits, zero-padded to one column tile
         l_h4.load(ph.h4_p, ph.b4, wave, lane, A);
         lds_barrier();
         CM_PROBE(12);
@@ -680,7 +684,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &a, const TrunkW &tw, con
         l_h4.template run<false>(E, SE, bufA, SA, RT, wave, lane);
         lds_barrier();
         CM_PROBE(14);
-        for (int r = tid; r < rows; r += TPB) {
+        for (int r = tid; r < rows; r += TPBW) {
             float lg[MAX_ACT], p[MAX_ACT];
             const float *x = bufA + (size_t)r * SA;
 #pragma unroll
@@ -730,14 +734,14 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &a, const TrunkW &tw, con
     } else {
         l_x1.template run<true>(H, SE, T, SE, RT, wave, lane);
         lds_barrier();
-        for (int r = tid; r < rows; r += TPB) {
+        for (int r = tid; r < rows; r += TPBW) {
             const float *x = T + (size_t)r * SE;
             float acc = chd.b2 ? chd.b2[0] : 0.0f;
             for (int k = 0; k < DH; ++k) acc = fmaf(x[k], chd.w2t[k], acc);
             rs[r] = acc;
         }
         lds_barrier();
-        for (int e = tid; e < envs; e += TPB) {
+        for (int e = tid; e < envs; e += TPBW) {
             float v = 0.0f;
             for (int i = 0; i < N; ++i) v += rs[e * N + i];
             a.values[s0 + e] = v;

@@ -27,7 +27,7 @@ if len(sys.argv) > 1:
     print(f"stop={os.environ.get('COMMARL_FWD_STOP','0')}: {e0.elapsed_time(e1)/200*1e3:.1f} us")
 else:
     for cfg in os.environ.get("CFGS", "pp_map10").split(","):
-        for rows in os.environ.get("ROWS", "32").split(","):
+        for rows in os.environ.get("ROWS", "0").split(","):
             print("rows per workgroup", rows, flush=True)
             for k in [int(x) for x in os.environ.get("STOPS", "1,2,3,4,5,6,7,0").split(",")]:
                 subprocess.run([sys.executable, __file__, "child", cfg],
