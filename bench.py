@@ -30,7 +30,8 @@ CONFIGS = {
     "co_map20": dict(scenario="co", map=20, sen=2, n_agents=24, n_preys=0, load=2, max_env_steps=400, loss=0.0,
                      envs=2048, label="Coverage map=20 sen=2 den=0.06 (N=24), Comm-DP GNN policy"),
     "pp_map30": dict(scenario="pp", map=30, sen=2, n_agents=72, n_preys=72, load=4, max_env_steps=200, loss=0.0,
-                     envs=1024, label="PredatorPrey map=30 sen=2 den=0.08 cap=4 (N=M=72), Comm-DP GNN policy"),
+                     envs=1024, streams=1,      # 8-wave policy workgroups fill the CUs' registers: shards cannot overlap
+                     label="PredatorPrey map=30 sen=2 den=0.08 cap=4 (N=M=72), Comm-DP GNN policy"),
     "co_map30": dict(scenario="co", map=30, sen=2, n_agents=54, n_preys=0, load=2, max_env_steps=400, loss=0.3,
                      envs=1024, label="Coverage map=30 sen=2 den=0.06 loss=0.3 IID (N=54), Comm-DP GNN policy"),
 }
@@ -144,7 +145,8 @@ def main():
     ap.add_argument("--config", default="pp_map10", choices=sorted(CONFIGS))
     ap.add_argument("--envs", type=int, default=None, help="envs per GPU (default: the config's)")
     ap.add_argument("--chunk", type=int, default=50, help="steps per captured hipGraph")
-    ap.add_argument("--streams", type=int, default=2, help="independent env shards per GPU, one HIP stream each")
+    ap.add_argument("--streams", type=int, default=None,
+                    help="independent env shards per GPU, one HIP stream each (default: the config's, normally 2)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-loop", action="store_true")
@@ -181,7 +183,8 @@ def main():
     B = args.envs or c["envs"]
     c["envs"] = B
     env = E.GridEnvBatch(c["scenario"], env_params(c), B, device=dev, seed=args.seed, env_id_offset=rank * B)
-    ns = args.streams if (args.streams > 1 and B % args.streams == 0) else 1
+    n_streams = args.streams if args.streams is not None else c.get("streams", 2)
+    ns = n_streams if (n_streams > 1 and B % n_streams == 0) else 1
     if ns > 1:      # the same B envs (same global ids, same Philox streams) as `ns` shards, each on its own stream
         shards = [E.GridEnvBatch(c["scenario"], env_params(c), B // ns, device=dev, seed=args.seed,
                                  env_id_offset=rank * B + k * (B // ns)) for k in range(ns)]
