@@ -312,6 +312,8 @@ def main():
             out["train_loop"] = train_loop_measurement(env, policy, c, spec, world, rank, dev, args.seed, kind=args.policy)
         except ImportError:
             out["train_loop"] = None
+        except Exception as e:                      # the headline (rollout) line must survive a failure of this extra leg
+            out["train_loop"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
