@@ -112,21 +112,39 @@ struct Layer {
             v4f acc0[NCT], acc1[NCT];
 #pragma unroll
             for (int t = 0; t < NCT; ++t) { acc0[t] = (v4f){ 0.f, 0.f, 0.f, 0.f }; acc1[t] = (v4f){ 0.f, 0.f, 0.f, 0.f }; }
+            if (hasB) {
 #pragma unroll
-            for (int kq = 0; kq < KS / 4; ++kq) {
-                const float x0[4] = { a0[kq].x, a0[kq].y, a0[kq].z, a0[kq].w };
-                const float x1[4] = { a1[kq].x, a1[kq].y, a1[kq].z, a1[kq].w };
+                for (int kq = 0; kq < KS / 4; ++kq) {
+                    const float x0[4] = { a0[kq].x, a0[kq].y, a0[kq].z, a0[kq].w };
+                    const float x1[4] = { a1[kq].x, a1[kq].y, a1[kq].z, a1[kq].w };
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < 4; ++j) {
 #pragma unroll
-                    for (int t = 0; t < NCT; ++t) {
+                        for (int t = 0; t < NCT; ++t) {
 #if (CM_DIAG & 4)
-                        acc0[t][j] += x0[j] * b[t][4 * kq + j];                      // diagnostic: no matrix-core work
-                        acc1[t][j] += x1[j] * b[t][4 * kq + j];
+                            acc0[t][j] += x0[j] * b[t][4 * kq + j];                  // diagnostic: no matrix-core work
+                            acc1[t][j] += x1[j] * b[t][4 * kq + j];
 #else
-                        acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[j], b[t][4 * kq + j], acc0[t], 0, 0, 0);
-                        acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[j], b[t][4 * kq + j], acc1[t], 0, 0, 0);
+                            acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[j], b[t][4 * kq + j], acc0[t], 0, 0, 0);
+                            acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[j], b[t][4 * kq + j], acc1[t], 0, 0, 0);
 #endif
+                        }
+                    }
+                }
+            } else {                                    // odd tile count: the unpaired last tile runs a single chain
+#pragma unroll
+                for (int kq = 0; kq < KS / 4; ++kq) {
+                    const float x0[4] = { a0[kq].x, a0[kq].y, a0[kq].z, a0[kq].w };
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                        for (int t = 0; t < NCT; ++t) {
+#if (CM_DIAG & 4)
+                            acc0[t][j] += x0[j] * b[t][4 * kq + j];
+#else
+                            acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[j], b[t][4 * kq + j], acc0[t], 0, 0, 0);
+#endif
+                        }
                     }
                 }
             }
