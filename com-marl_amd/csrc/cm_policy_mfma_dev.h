@@ -509,10 +509,11 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &a, const TrunkW &tw, con
             for (int j = sl; j < N; j += 16) mx = fmaxf(mx, m[j]);
             mx = row16_max(mx);
             float sum = 0.0f;
-            for (int j = sl; j < N; j += 16) { const float ex = expf(m[j] - mx); sum += ex; if (r0 + (tid >> 4) < rows) m[j] = ex; }
+            for (int j = sl; j < N; j += 16) { const float ex = __builtin_amdgcn_exp2f((m[j] - mx) * 1.4426950408889634f); sum += ex; if (r0 + (tid >> 4) < rows) m[j] = ex; }   // hardware exp2 / rcp: 1 ulp
             sum = row16_sum(sum);
+            const float rsum = __builtin_amdgcn_rcpf(sum);
             if (r0 + (tid >> 4) < rows)
-                for (int j = sl; j < N; j += 16) m[j] = m[j] / sum;
+                for (int j = sl; j < N; j += 16) m[j] = m[j] * rsum;
         }
     } else {
         for (int k = tid; k < envs * NN; k += TPBW) {
@@ -597,11 +598,11 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &a, const TrunkW &tw, con
                             v[jb] = (live && j < N) ? mr[j] * (masked ? mk[rb * JB + jb] : 1.0f) : 0.0f;
                             sum += v[jb];
                         }
-                        const float den = row16_sum(sum) + 1e-12f;
+                        const float rden = __builtin_amdgcn_rcpf(row16_sum(sum) + 1e-12f);
                         if (live) {
                             float *ar = Amat + (size_t)r * NPA;
 #pragma unroll
-                            for (int jb = 0; jb < JB; ++jb) { const int j = jb * 16 + sl; if (j < NPA) ar[j] = j < N ? v[jb] / den : 0.0f; }
+                            for (int jb = 0; jb < JB; ++jb) { const int j = jb * 16 + sl; if (j < NPA) ar[j] = j < N ? v[jb] * rden : 0.0f; }
                         }
                     }
                 }
