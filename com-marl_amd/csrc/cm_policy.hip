@@ -185,7 +185,7 @@ __global__ __launch_bounds__(TPB) void fwd_kernel(FwdArgs a, TrunkW tw, PolHead 
         __syncthreads();
     }
     // ---- residual (comm_categorical_mlp_policy.py:74-77) ----
-    for (int k = tid; k < rows * EMB; k += TPB) { const int r = k >> 6, o = k & 63; H[(size_t)r * SE + o] = (L > 0 ? H[(size_t)r * SE + o] : 0.0f) + ((a.no_residual && L > 0) ? 0.0f : E[(size_t)r * SE + o]); }
+    for (int k = tid; k < rows * EMB; k += TPB) { const int r = k >> 6, o = k & 63; H[(size_t)r * SE + o] = (L > 0 ? H[(size_t)r * SE + o] : E[(size_t)r * SE + o]) + (a.no_residual ? 0.0f : E[(size_t)r * SE + o]); }   // embeddings[-1] is E when there are no hops
     __syncthreads();
 
     if (HEAD == 0) {

@@ -677,8 +677,9 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &a, const TrunkW &tw, con
     if (a.stop == 6) return;
     CM_PROBE(10);
     // ---- residual ----
-    if (L == 0) {                                       // no hops: x = E (the hop epilogue adds the residual otherwise)
-        for (int k = tid; k < rows * EMB; k += TPBW) { const int r = k >> 6, o = k & 63; H[(size_t)r * SE + o] = E[(size_t)r * SE + o]; }
+    if (L == 0) {      // no hops: embeddings[-1] is E itself, so x = E + E with the residual (:74-77), else E
+        const float f = a.no_residual ? 1.0f : 2.0f;    // (with hops the last hop's epilogue adds the residual)
+        for (int k = tid; k < rows * EMB; k += TPBW) { const int r = k >> 6, o = k & 63; H[(size_t)r * SE + o] = f * E[(size_t)r * SE + o]; }
         lds_barrier();
     }
 

@@ -229,7 +229,9 @@ def test_linear_weight_gradient_kernel(R, IN, OUT, torch_cuda):
 
 
 @pytest.mark.parametrize("d,n_agents,residual,hops", [(21, 4, False, 2), (100, 4, True, 2), (100, 6, False, 1), (29, 3, True, 3),
-                                                      (77, 24, False, 2), (53, 72, True, 1)])
+                                                      (77, 24, False, 2), (53, 72, True, 1), (21, 8, True, 2), (29, 16, True, 2),
+                                                      (53, 20, False, 2), (77, 32, True, 2), (12, 36, True, 2), (40, 80, False, 3),
+                                                      (21, 4, True, 0), (77, 54, True, 0), (100, 5, True, 0), (21, 4, False, 0)])
 def test_fused_kernels_vs_autograd_path(d, n_agents, residual, hops, torch_cuda):
     """residual on/off, hop counts, odd team sizes and obs dims without an MFMA build (d=100 -> the generic
     VALU kernel): the fused forward must equal the autograd path (torch GEMMs + masked_aggregate)."""
@@ -254,3 +256,39 @@ def test_fused_kernels_vs_autograd_path(d, n_agents, residual, hops, torch_cuda)
     np.testing.assert_allclose(attn.cpu().numpy(), a_ref.cpu().numpy(), **TOL)
     v = crit.values_device(obs, adj, ch)
     np.testing.assert_allclose(v.cpu().numpy(), v_ref.cpu().numpy(), rtol=1e-5, atol=1e-5 * n_agents)
+
+
+@pytest.mark.parametrize("n_agents,d", [(4, 21), (24, 77), (54, 77)])
+def test_operand_pack_path_equals_plain_weight_path(n_agents, d, torch_cuda):
+    """cm_policy_forward with the matrix-core operand pack (MFMA kernels) vs without it (mfma_pack = NULL: the generic
+    VALU kernel reads the plain [in,out] weights): same net, same inputs, results within the f32 reordering error."""
+    import ctypes as C
+    torch = torch_cuda
+    from com_marl_amd import _lib as L, nets
+    from com_marl_amd.envs import EnvSpec, _Box, _Discrete
+    torch.manual_seed(n_agents)
+    spec = EnvSpec(_Box(np.zeros(d * n_agents), np.ones(d * n_agents)), _Discrete(5))
+    pol = nets.CommCategoricalMLPPolicy(spec, n_agents=n_agents, device="cuda:0")
+    S = 19
+    obs = torch.rand(S, n_agents * d, device="cuda:0")
+    _, p_pack, a_pack = pol.act_device(obs, None, None, None, want_actions=False)
+    w = pol._weights_struct()
+    assert w.mfma_pack and L.lib().cm_policy_pack_bytes(C.byref(w)) == pol._mfma.numel() * 4
+    w.mfma_pack = None
+    probs = torch.empty(S, n_agents, 5, device="cuda:0")
+    attn = torch.empty(S, n_agents, n_agents, device="cuda:0")
+    L.check(L.lib().cm_policy_forward(C.byref(w), S, obs.data_ptr(), None, None, None, 1, 0, 0, None, 0, None,
+                                      probs.data_ptr(), attn.data_ptr(), None), "cm_policy_forward (plain weights)")
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(p_pack.cpu().numpy(), probs.cpu().numpy(), **TOL)
+    np.testing.assert_allclose(a_pack.cpu().numpy(), attn.cpu().numpy(), **TOL)
+    # the pack follows in-place weight updates (same buffer, rewritten by sync_weights)
+    ptr0 = pol._mfma.data_ptr()
+    with torch.no_grad():
+        for prm in pol.parameters():
+            prm.mul_(0.5)
+    _, p2, _ = pol.act_device(obs, None, None, None, want_actions=False)
+    assert pol._mfma.data_ptr() == ptr0 and (p2 - p_pack).abs().max() > 1e-4
+    with torch.no_grad():
+        p_ref, _ = pol._probs(obs, None, None, None)
+    np.testing.assert_allclose(p2.cpu().numpy(), p_ref.cpu().numpy(), **TOL)
