@@ -657,7 +657,7 @@ void cmo_policy_forward(const cmo_policy_weights *w, int S, const float *obs, co
             comm_trunk(d, N, L, EH, E, w->enc_w1, w->enc_b1, w->enc_w2, w->enc_b2, w->attn_w, w->gcn_w, w->gcn_b,
                        obs + (size_t)s * N * d, dist_adj + (size_t)s * N * N, channels + (size_t)s * L * N * N, emb,
                        att, scr);
-            for (int k = 0; k < N * E; ++k) x[k] = emb[k] + emb[(size_t)L * N * E + k];          /* residual :74-77 */
+            for (int k = 0; k < N * E; ++k) x[k] = (w->no_residual ? 0.0f : emb[k]) + emb[(size_t)L * N * E + k];   /* :74-77 */
             linear(N, E, w->h1, x, w->hd_w1, w->hd_b1, 1, a1);
             linear(N, w->h1, w->h2, a1, w->hd_w2, w->hd_b2, 1, a2);
             linear(N, w->h2, w->h3, a2, w->hd_w3, w->hd_b3, 1, a3);
@@ -753,7 +753,7 @@ void cmo_critic_forward(const cmo_critic_weights *w, int S, const float *obs, co
             comm_trunk(d, N, L, EH, E, w->enc_w1, w->enc_b1, w->enc_w2, w->enc_b2, w->attn_w, w->gcn_w, w->gcn_b,
                        obs + (size_t)s * N * d, dist_adj + (size_t)s * N * N, channels + (size_t)s * L * N * N, emb,
                        att, scr);
-            for (int k = 0; k < N * E; ++k) x[k] = emb[k] + emb[(size_t)L * N * E + k];
+            for (int k = 0; k < N * E; ++k) x[k] = (w->no_residual ? 0.0f : emb[k]) + emb[(size_t)L * N * E + k];
             linear(N, E, DH, x, w->dec_w1, w->dec_b1, 1, a1);
             linear(N, DH, 1, a1, w->dec_w2, w->dec_b2, 0, v);
             float sum = 0.0f;

@@ -405,14 +405,16 @@ def record_adj_ties(ns, seed=3):
 # --------------------------------------------------------------------------------------
 # policy / critic / PPO-math fixtures
 # --------------------------------------------------------------------------------------
-def record_policy(ns, env_fix, n_agents, seed=1, take=6):
-    """Policy + critic forward at a seeded state_dict on observations from an env fixture."""
+def record_policy(ns, env_fix, n_agents, seed=1, take=6, n_hops=None, residual=True):
+    """Policy + critic forward at a seeded state_dict on observations from an env fixture.  n_hops / residual:
+    non-default GCN depth (0 = no message passing: embeddings[-1] is the encoder output itself) and skip connection."""
     torch.manual_seed(seed)
     T1, B = env_fix['obs'].shape[:2]
     d_total = env_fix['obs'].shape[2]
     spec = ref_loader.make_env_spec(d_total)
-    pol = ns.CommCategoricalMLPPolicy(spec, n_agents=n_agents)
-    crit = ns.CommBaseCritic(spec, n_agents=n_agents)
+    kw = {} if n_hops is None else dict(n_gcn_layers=n_hops)
+    pol = ns.CommCategoricalMLPPolicy(spec, n_agents=n_agents, residual=residual, **kw)
+    crit = ns.CommBaseCritic(spec, n_agents=n_agents, residual=residual, **kw)
     # make biases non-zero so that bias handling is actually pinned
     with torch.no_grad():
         for net in (pol, crit):
@@ -426,6 +428,9 @@ def record_policy(ns, env_fix, n_agents, seed=1, take=6):
     S = obs.shape[0]
     avail = np.ones((S, n_agents * 5), dtype=np.float32)
     rng = np.random.RandomState(seed)
+    if n_hops is not None and n_hops != ch.shape[1]:                     # other depth: seeded random link masks
+        ch = (rng.rand(S, n_hops, n_agents, n_agents) < 0.8).astype(np.float32)
+        ch[:, :, np.arange(n_agents), np.arange(n_agents)] = 1.0
     avail_masked = avail.copy().reshape(S, n_agents, 5)
     avail_masked[rng.rand(S, n_agents) < 0.3, 1] = 0                     # forbid action 1 sometimes
     avail_masked = avail_masked.reshape(S, -1)
@@ -448,7 +453,8 @@ def record_policy(ns, env_fix, n_agents, seed=1, take=6):
         returns = torch.Tensor(rng.randn(S).astype(np.float32) * 3)
         out['critic_loss'] = crit.compute_loss(tobs, returns, tadj, tch).numpy()
         out['returns'] = returns.numpy()
-    out.update(obs=obs.astype(np.float32), adj=adj, channels=ch, avail_masked=avail_masked, actions=acts)
+    out.update(obs=obs.astype(np.float32), adj=adj, channels=ch, avail_masked=avail_masked, actions=acts,
+               residual=np.int32(residual))
     for name, p in pol.state_dict().items():
         out['pol.' + name] = p.numpy()
     for name, p in crit.state_dict().items():
@@ -756,6 +762,9 @@ def main():
     save('policy_co_map20', record_policy(ns, fx['co_map20'], 24, take=3))
     save('policy_pp_map30', record_policy(ns, fx['pp_map30_cap4'], 72, take=2))
     save('policy_co_map30_iid', record_policy(ns, fx['co_map30_iid'], 54, take=2))
+    save('policy_pp_map10_hops0', record_policy(ns, fx['pp_map10_cap2'], 4, seed=2, take=4, n_hops=0))
+    save('policy_pp_map10_hops1_nores', record_policy(ns, fx['pp_map10_cap2'], 4, seed=3, take=4, n_hops=1, residual=False))
+    save('policy_co_map20_hops3', record_policy(ns, fx['co_map20'], 24, seed=4, take=2, n_hops=3))
     late(save, args, ns)
 
 

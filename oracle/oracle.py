@@ -57,13 +57,14 @@ class Out(C.Structure):
 
 class PolicyW(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("d", "n_agents", "n_hops", "enc_hidden", "emb", "h1", "h2", "h3",
-                                         "n_act", "_pad")] + [
+                                         "n_act", "no_residual")] + [
         (n, C.c_void_p) for n in ("enc_w1", "enc_b1", "enc_w2", "enc_b2", "attn_w", "gcn_w", "gcn_b", "hd_w1",
                                   "hd_b1", "hd_w2", "hd_b2", "hd_w3", "hd_b3", "hd_w4", "hd_b4")]
 
 
 class CriticW(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("d", "n_agents", "n_hops", "enc_hidden", "emb", "dec_hidden")] + [
+    _fields_ = [(n, C.c_int32) for n in ("d", "n_agents", "n_hops", "enc_hidden", "emb", "dec_hidden", "no_residual",
+                                         "_pad")] + [
         (n, C.c_void_p) for n in ("enc_w1", "enc_b1", "enc_w2", "enc_b2", "attn_w", "gcn_w", "gcn_b", "dec_w1",
                                   "dec_b1", "dec_w2", "dec_b2")]
 
@@ -228,12 +229,14 @@ def _f32(a):
 
 
 def _gcn_stack(sd, n_hops):
+    if n_hops == 0:
+        return np.zeros((1, 1, 1), np.float32), np.zeros((1, 1), np.float32)
     w = np.stack([_f32(sd[f"gcn_layers.{l}.weight"]) for l in range(n_hops)])
     b = np.stack([_f32(sd[f"gcn_layers.{l}.bias"]) for l in range(n_hops)])
     return np.ascontiguousarray(w), np.ascontiguousarray(b)
 
 
-def policy_forward(sd, obs, avail, dist_adj, channels, n_agents, n_threads=1, want_emb=False):
+def policy_forward(sd, obs, avail, dist_adj, channels, n_agents, n_threads=1, want_emb=False, residual=True):
     """sd: reference-named state_dict (numpy). obs [S,N*d] or [S,N,d]; returns probs [S,N,A], attn [S,N,N]."""
     S = obs.shape[0]
     N = n_agents
@@ -246,6 +249,7 @@ def policy_forward(sd, obs, avail, dist_adj, channels, n_agents, n_threads=1, wa
     w = PolicyW()
     w.d, w.n_agents, w.n_hops, w.enc_hidden, w.emb = d, N, n_hops, arrs["enc_w1"].shape[0], arrs["enc_w2"].shape[0]
     w.h1, w.h2, w.h3, w.n_act = arrs["hd_w1"].shape[0], arrs["hd_w2"].shape[0], arrs["hd_w3"].shape[0], A
+    w.no_residual = 0 if residual else 1
     for k, a in arrs.items():
         setattr(w, k, _p(a))
     avail = _f32(avail).reshape(S, N, A)
@@ -259,7 +263,7 @@ def policy_forward(sd, obs, avail, dist_adj, channels, n_agents, n_threads=1, wa
     return (probs, attn, emb) if want_emb else (probs, attn)
 
 
-def critic_forward(sd, obs, dist_adj, channels, n_agents, n_threads=1):
+def critic_forward(sd, obs, dist_adj, channels, n_agents, n_threads=1, residual=True):
     S = obs.shape[0]
     N = n_agents
     obs = _f32(obs).reshape(S, N, -1)
@@ -269,6 +273,7 @@ def critic_forward(sd, obs, dist_adj, channels, n_agents, n_threads=1):
     w = CriticW()
     w.d, w.n_agents, w.n_hops = obs.shape[2], N, n_hops
     w.enc_hidden, w.emb, w.dec_hidden = arrs["enc_w1"].shape[0], arrs["enc_w2"].shape[0], arrs["dec_w1"].shape[0]
+    w.no_residual = 0 if residual else 1
     for k, a in arrs.items():
         setattr(w, k, _p(a))
     adj = _f32(dist_adj).reshape(S, N, N)

@@ -26,8 +26,10 @@ def build_nets(z, n_agents, torch):
     from com_marl_amd.envs import EnvSpec, _Box, _Discrete
     d_total = z["obs"].shape[1]
     spec = EnvSpec(_Box(np.zeros(d_total), np.ones(d_total)), _Discrete(5))
-    pol = nets.CommCategoricalMLPPolicy(spec, n_agents=n_agents, device="cuda:0")
-    crit = nets.CommBaseCritic(spec, n_agents=n_agents, device="cuda:0")
+    hops = z["channels"].shape[1]
+    res = bool(z["residual"]) if "residual" in z.files else True
+    pol = nets.CommCategoricalMLPPolicy(spec, n_agents=n_agents, n_gcn_layers=hops, residual=res, device="cuda:0")
+    crit = nets.CommBaseCritic(spec, n_agents=n_agents, n_gcn_layers=hops, residual=res, device="cuda:0")
     # load the REFERENCE state_dict by the reference's parameter names (strict)
     pol.load_state_dict({k[4:]: torch.as_tensor(z[k]) for k in z.files if k.startswith("pol.")}, strict=True)
     crit.load_state_dict({k[5:]: torch.as_tensor(z[k]) for k in z.files if k.startswith("crit.")}, strict=True)

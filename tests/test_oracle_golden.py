@@ -121,7 +121,9 @@ def test_philox_known_answers():
 
 
 POLICY_FIXTURES = [("policy_pp_map10", 4), ("policy_co_map20", 24), ("policy_pp_map30", 72),
-                   ("policy_co_map30_iid", 54)]
+                   ("policy_co_map30_iid", 54),
+                   # GCN depth 0 / 1 / 3 and the skip connection switched off (comm_categorical_mlp_policy.py:74-77)
+                   ("policy_pp_map10_hops0", 4), ("policy_pp_map10_hops1_nores", 4), ("policy_co_map20_hops3", 24)]
 
 
 @pytest.mark.parametrize("name,n_agents", POLICY_FIXTURES)
@@ -131,13 +133,14 @@ def test_policy_critic_forward(name, n_agents):
     crit = {k[5:]: z[k] for k in z.files if k.startswith("crit.")}
     S = z["obs"].shape[0]
     ones = np.ones((S, n_agents, 5), np.float32)
-    probs, attn, emb = O.policy_forward(pol, z["obs"], ones, z["adj"], z["channels"], n_agents, want_emb=True)
+    res = bool(z["residual"]) if "residual" in z.files else True
+    probs, attn, emb = O.policy_forward(pol, z["obs"], ones, z["adj"], z["channels"], n_agents, want_emb=True, residual=res)
     tol = dict(rtol=1e-5, atol=1e-5)      # north_star float tolerance
     np.testing.assert_allclose(probs, z["probs"], **tol)
     np.testing.assert_allclose(attn, z["attn"], **tol)
     for l in range(emb.shape[1]):
         np.testing.assert_allclose(emb[:, l], z[f"emb{l}"], **tol)
-    probs_m, _ = O.policy_forward(pol, z["obs"], z["avail_masked"], z["adj"], z["channels"], n_agents)
+    probs_m, _ = O.policy_forward(pol, z["obs"], z["avail_masked"], z["adj"], z["channels"], n_agents, residual=res)
     np.testing.assert_allclose(probs_m, z["probs_masked"], **tol)
     # entropy = mean over agents, log-lik = sum over agents (comm_categorical_mlp_policy.py:121-137)
     ent = -(probs * np.log(probs)).sum(-1).mean(-1)
@@ -145,7 +148,7 @@ def test_policy_critic_forward(name, n_agents):
     a = z["actions"]
     ll = np.log(np.take_along_axis(probs, a[..., None], -1)[..., 0]).sum(-1)
     np.testing.assert_allclose(ll, z["loglik"], rtol=1e-5, atol=1e-5 * n_agents)
-    v = O.critic_forward(crit, z["obs"], z["adj"], z["channels"], n_agents)
+    v = O.critic_forward(crit, z["obs"], z["adj"], z["channels"], n_agents, residual=res)
     np.testing.assert_allclose(v, z["values"], rtol=1e-5, atol=1e-5 * n_agents)
     closs = O.critic_loss(v, z["returns"], log_std=float(crit["baseline_aggregator._init_std"][0]))
     np.testing.assert_allclose(closs, z["critic_loss"], rtol=1e-5)
