@@ -130,6 +130,19 @@ def test_transfer_scale_eval_small_team_weights_on_a_larger_map(torch_cuda):
         np.testing.assert_allclose(data[b][1]["nodeDeg"], degs[b], rtol=1e-6)
 
 
+def test_eval_plays_several_rounds_when_more_episodes_than_envs(torch_cuda):
+    from com_marl_amd.evaluate import eval_model, eval_model_co, VECTORS
+    env, pol, _ = _setup(torch_cuda, "co", 3, 7)
+    data, succ, rew, opt = eval_model_co(env, pol, 0, n_eval_episodes=8, max_env_steps=7)      # 3 rounds of 3 envs
+    assert len(data) == 8 and len(succ) == 8 and all(len(rew[v]) == 8 for v in VECTORS)
+    assert opt == [env.bound_return] * 8                                                      # eval_co.py:79,101
+    assert env.eval_n_epi == 8 and all(1 <= len(d[1]["reward"]) <= 7 for d in data)
+    # rounds are different episodes: the Philox reset counter advances between them
+    assert any(data[i][1]["reward"] != data[i + 3][1]["reward"] or data[i][1]["variable"] != data[i + 3][1]["variable"]
+               for i in range(3))
+    assert np.isfinite(env.last_eval_average_reward)
+
+
 def test_eval_refuses_render_and_honours_flag(torch_cuda):
     from com_marl_amd.evaluate import eval_model
     env, pol, _ = _setup(torch_cuda, "pp", 4, 10)
