@@ -30,8 +30,7 @@ CONFIGS = {
     "co_map20": dict(scenario="co", map=20, sen=2, n_agents=24, n_preys=0, load=2, max_env_steps=400, loss=0.0,
                      envs=2048, label="Coverage map=20 sen=2 den=0.06 (N=24), Comm-DP GNN policy"),
     "pp_map30": dict(scenario="pp", map=30, sen=2, n_agents=72, n_preys=72, load=4, max_env_steps=200, loss=0.0,
-                     envs=1024, streams=1,      # 8-wave policy workgroups fill the CUs' registers: shards cannot overlap
-                     label="PredatorPrey map=30 sen=2 den=0.08 cap=4 (N=M=72), Comm-DP GNN policy"),
+                     envs=1024, label="PredatorPrey map=30 sen=2 den=0.08 cap=4 (N=M=72), Comm-DP GNN policy"),
     "co_map30": dict(scenario="co", map=30, sen=2, n_agents=54, n_preys=0, load=2, max_env_steps=400, loss=0.3,
                      envs=1024, label="Coverage map=30 sen=2 den=0.06 loss=0.3 IID (N=54), Comm-DP GNN policy"),
 }

@@ -348,7 +348,7 @@ __device__ __forceinline__ void emit(const EnvDev &p, const Lds l, const Rng rng
 template <int SCEN, int LPE>
 __device__ __forceinline__ void env_body(const EnvDev &p, const int32_t *__restrict__ actions, const int32_t *act_lds,
                                          const cm_rng_tape &tape, const cm_step_out &out, int reset_only, int grp, int b_raw,
-                                         bool grp_live, int lds_base) {
+                                         bool grp_live, int lds_base, int *defer = nullptr) {
     Grp<LPE> g;
     g.sub = (threadIdx.x & (WAVE - 1)) / LPE; g.sl = threadIdx.x % LPE;
     const int sl = g.sl;
@@ -364,6 +364,7 @@ __device__ __forceinline__ void env_body(const EnvDev &p, const int32_t *__restr
         do_reset<SCEN, LPE>(p, l, rng, tape, b, g, true);
         if (!valid) return;
         if (sl == 0) { p.step_count[b] = 0; if (SCEN == CM_CO) p.total_capture[b] = 0; p.rng_step[b] = rng.step + 1; }
+        if (defer) { if (sl == 0) { defer[1] = 0; defer[2] = 1; defer[3] = (int)rng.step; defer[0] = 1; } return; }
         emit<SCEN, LPE>(p, l, rng, tape, o, b, g, 0, 1);
         return;
     }
@@ -567,6 +568,9 @@ __device__ __forceinline__ void env_body(const EnvDev &p, const int32_t *__restr
         p.success[b] = succ;
         if (o.success) o.success[b] = succ;
     }
+    // wide kernel: the emission (order-independent, the bulk of the instructions for large teams) is done by all the
+    // workgroup's waves after this wave has left the state in LDS; hand over (step count, slot, Philox step)
+    if (defer) { if (sl == 0) { defer[1] = step_count; defer[2] = done ? 1 : 0; defer[3] = (int)rng.step; defer[0] = 1; } return; }
     emit<SCEN, LPE>(p, l, rng, tape, o, b, g, step_count, done ? 1 : 0);
 }
 
