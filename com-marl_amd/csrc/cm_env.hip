@@ -43,25 +43,30 @@ __global__ __launch_bounds__(WAVE) void env_kernel(EnvDev p, const int32_t *__re
     env_body<SCEN, LPE>(p, actions, nullptr, tape, out, reset_only, grp, blockIdx.x * G + grp, true, 0);
 }
 
-// Wide form for large teams (LPE == 64): one env per 256-thread workgroup.  Wave 0 runs the step - everything order-
-// dependent is wave-local - and leaves the new state in LDS; then all four waves emit observations, adjacency, channel
-// draws and the state write-back (for N = 54 with an IID channel that is ~1500 Philox calls and ~13 k stores per env and
-// step: 56 of the narrow kernel's 78 us).
-template <int SCEN>
+// Wide form: a 256-thread workgroup for the G = 64 / LPE envs that share one wave in the narrow kernel.  Wave 0 runs
+// the step of those envs - everything order-dependent is wave-local - and leaves the new state in LDS; then all four
+// waves emit observations, adjacency, channel draws and the state write-back, 256 / G lanes per env.  Pays whenever
+// the narrow kernel cannot put more than one wave on a SIMD (the step is then one wave's instruction stream): for
+// N = 54 with an IID channel the emission is ~1500 Philox calls and ~13 k stores per env, 56 of the narrow 78 us.
+template <int SCEN, int LPE>
 __global__ __launch_bounds__(256) void env_kernel_wide(EnvDev p, const int32_t *__restrict__ actions, cm_rng_tape tape,
                                                       cm_step_out out, int reset_only) {
-    __shared__ int hand[4];                            // [0] emit?  [1] step count  [2] comm slot  [3] Philox step
-    if (threadIdx.x == 0) hand[0] = 0;
+    constexpr int G = WAVE / LPE, EL = 256 / G;        // envs per workgroup, emission lanes per env
+    __shared__ int hand[4 * G];                        // per env: [0] emit?  [1] step count  [2] comm slot  [3] Philox step
+    if (threadIdx.x < 4 * G) hand[threadIdx.x] = 0;
     __syncthreads();
-    const int b = blockIdx.x;
-    if (threadIdx.x < WAVE) env_body<SCEN, 64>(p, actions, nullptr, tape, out, reset_only, 0, b, true, 0, hand);
+    if (threadIdx.x < WAVE) {
+        const int grp = threadIdx.x / LPE;
+        env_body<SCEN, LPE>(p, actions, nullptr, tape, out, reset_only, grp, blockIdx.x * G + grp, true, 0, hand + 4 * grp);
+    }
     __syncthreads();
-    if (!hand[0]) return;
-    Grp<256> g;
-    g.sub = 0; g.sl = threadIdx.x;
-    const Lds l = make_lds(p.S, p.N, p.M, 0, p.status);
-    const Rng rng{ (uint32_t)(p.env_id_offset + b), (uint32_t)hand[3], p.key0, p.key1 };
-    emit<SCEN, 256>(p, l, rng, tape, out, b, g, hand[1], hand[2]);
+    const int grp = threadIdx.x / EL, b = blockIdx.x * G + grp;
+    if (b >= p.B || !hand[4 * grp]) return;
+    Grp<EL> g;
+    g.sub = 0; g.sl = threadIdx.x % EL;
+    const Lds l = make_lds(p.S, p.N, p.M, p.lds_env * grp, p.status);
+    const Rng rng{ (uint32_t)(p.env_id_offset + b), (uint32_t)hand[4 * grp + 3], p.key0, p.key1 };
+    emit<SCEN, EL>(p, l, rng, tape, out, b, g, hand[4 * grp + 1], hand[4 * grp + 2]);
 }
 
 __global__ void fill_const_kernel(float *adj, float *ch, int B, int N, int L, int channel) {
@@ -262,11 +267,17 @@ static int launch(cm_env_t h, const int32_t *actions, const cm_rng_tape *tape, c
     const dim3 grid((d.B + G - 1) / G), block(WAVE);
     const hipStream_t st = (hipStream_t)stream;
     static const bool wide_on = [] { const char *e = getenv("COMMARL_ENV_WIDE"); return !(e && e[0] == '0'); }();
-    // large teams, when one wave per env cannot fill the 1024 SIMDs anyway: one env per 4-wave workgroup
-    // (measured at 1024 envs: N = 72 82 -> 66 us, N = 54 78 -> 56 us; at 2048 envs of N = 24 the narrow form wins, 36 vs 44 us)
+    // wide form when the narrow kernel would put at most one wave on each of the 1024 SIMDs (measured, narrow -> wide:
+    // N = 72 x 1024 envs 82 -> 66 us, N = 54 x 1024 78 -> 56 us; N = 24 x 2048 is two waves per SIMD and stays narrow, 36 vs 44 us)
+    const int G_ = WAVE / d.lpe;
+    // (small teams, LPE 16: 12.6 -> 13.1 us alone and 115 -> 101 M env-steps/s at config 2, the extra waves take the
+    // registers the overlapping policy kernel needs - large teams only)
     if (wide_on && d.lpe == 64 && d.B <= 1536) {
-        if (d.scen == CM_PP) hipLaunchKernelGGL((env_kernel_wide<CM_PP>), dim3(d.B), dim3(256), h->lds_bytes, st, d, actions, t, *out, reset_only);
-        else hipLaunchKernelGGL((env_kernel_wide<CM_CO>), dim3(d.B), dim3(256), h->lds_bytes, st, d, actions, t, *out, reset_only);
+        const dim3 wgrid((d.B + G_ - 1) / G_), wblock(256);
+#define CM_WIDE(SC, LP) hipLaunchKernelGGL((env_kernel_wide<SC, LP>), wgrid, wblock, h->lds_bytes, st, d, actions, t, *out, reset_only)
+        if (d.scen == CM_PP) { if (d.lpe == 16) CM_WIDE(CM_PP, 16); else if (d.lpe == 32) CM_WIDE(CM_PP, 32); else CM_WIDE(CM_PP, 64); }
+        else { if (d.lpe == 16) CM_WIDE(CM_CO, 16); else if (d.lpe == 32) CM_WIDE(CM_CO, 32); else CM_WIDE(CM_CO, 64); }
+#undef CM_WIDE
         CM_HIP(hipGetLastError());
         return CM_OK;
     }
