@@ -131,7 +131,21 @@ def cpu_baseline(c, seed, budget_s=12.0, kind="commdp"):
     for t in range(n):
         one(5 + t)
     dt = time.perf_counter() - t0
-    return dict(value=B * n / dt, unit="env-steps/s", cores=cores, kind="port",
+    # the same step on ONE thread (SURVEY.md §8d asks for both ends): a short sample, ~2 s
+    def one_st(t):
+        if kind == "commdp":
+            probs, _ = O.policy_forward(sd, env.obs, ones, env.dist_adj, env.channels, env.N, n_threads=1)
+        elif kind == "obsdp":
+            probs = O.dec_policy_forward(sd, env.obs.reshape(B, -1), ones, env.N)
+        else:
+            probs = O.cent_policy_forward(sd, env.obs.reshape(B, -1), ones, env.N)
+        env.step(O.sample_actions(probs, seed, 0, t), n_threads=1)
+    n1 = int(max(2, min(200, 2.0 / (per * cores))))
+    t0 = time.perf_counter()
+    for t in range(n1):
+        one_st(10000 + t)
+    dt1 = time.perf_counter() - t0
+    return dict(value=B * n / dt, unit="env-steps/s", cores=cores, kind="port", single_thread_value=B * n1 / dt1,
                 sample=f"{n} steps x {B} envs of the same workload (C oracle: env step + policy forward + sample, "
                        f"OpenMP over envs), {dt:.1f} s")
 
