@@ -111,7 +111,8 @@ struct Layer {
             for (int kq = 0; kq < KS / 4; ++kq) { a0[kq] = pa[4 * kq]; a1[kq] = pb[4 * kq]; }
             v4f acc0[NCT], acc1[NCT];
 #pragma unroll
-            for (int t = 0; t < NCT; ++t) { acc0[t] = (v4f){ 0.f, 0.f, 0.f, 0.f }; acc1[t] = (v4f){ 0.f, 0.f, 0.f, 0.f }; }
+            for (int t = 0; t < NCT; ++t) { acc0[t] = (v4f){ bv[t], bv[t], bv[t], bv[t] }; acc1[t] = acc0[t]; }   // bias rides in the accumulator:
+                                                                       // column = lane&15 is the same for a lane's 4 rows
             if (hasB) {
 #pragma unroll
                 for (int kq = 0; kq < KS / 4; ++kq) {
@@ -154,10 +155,10 @@ struct Layer {
                 const int col = (ct0 + t) * 16 + c;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float v0 = acc0[t][r] + bv[t];
+                    const float v0 = acc0[t][r];
                     out[(size_t)(rt * 16 + 4 * g + r) * out_stride + col] = TANH ? fast_tanh(v0) : v0;
                     if (hasB) {
-                        const float v1 = acc1[t][r] + bv[t];
+                        const float v1 = acc1[t][r];
                         out[(size_t)(rtB * 16 + 4 * g + r) * out_stride + col] = TANH ? fast_tanh(v1) : v1;
                     }
                 }
@@ -455,7 +456,13 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &a, const TrunkW &tw, con
                 v[r] = x * __builtin_amdgcn_rcpf(quad_sum(x) + 1e-12f);  // :102-103
             }
             quad_transpose(v, q, w);
-            v4f acc[2] = { (v4f){ 0.f, 0.f, 0.f, 0.f }, (v4f){ 0.f, 0.f, 0.f, 0.f } };
+            v4f acc[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {                                // bias rides in the accumulator
+                const float bv = l < 2 ? (l == 0 ? gbias[t] : gbias[2 + t])
+                                       : (tw.gcn_b ? tw.gcn_b[(size_t)l * EMB + 32 * ch + 16 * t + c] : 0.0f);
+                acc[t] = (v4f){ bv, bv, bv, bv };
+            }
             float hb[2][4];
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -471,11 +478,10 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &a, const TrunkW &tw, con
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const int col = 32 * ch + 16 * t + c;
-                    const float bv = l < 2 ? (l == 0 ? gbias[t] : gbias[2 + t]) : (tw.gcn_b ? tw.gcn_b[(size_t)l * EMB + col] : 0.0f);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const size_t o = (size_t)(rb + 4 * g + r) * SE + col;
-                        const float hv = fast_tanh(acc[t][r] + bv);      // graph_conv_module.py:65-70
+                        const float hv = fast_tanh(acc[t][r]);           // graph_conv_module.py:65-70
                         H[o] = (last && !a.no_residual) ? E[o] + hv : hv;        // policy :74-77
                     }
                 }
