@@ -64,7 +64,7 @@ MLP_MAX_LAYERS = 6
 class MlpWeights(C.Structure):
     _fields_ = [("in_dim", C.c_int32), ("n_layers", C.c_int32), ("out_dim", C.c_int32 * MLP_MAX_LAYERS),
                 ("tanh_mask", C.c_int32), ("_pad", C.c_int32), ("wt", C.c_void_p * MLP_MAX_LAYERS),
-                ("b", C.c_void_p * MLP_MAX_LAYERS)]
+                ("b", C.c_void_p * MLP_MAX_LAYERS), ("mfma_pack", C.c_void_p)]
 
 
 # every symbol include/commarl.h declares, with its signature
@@ -101,6 +101,8 @@ _SIGNATURES = {
     "cm_mlp_policy_forward": (C.c_int, [C.POINTER(MlpWeights), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                         C.c_void_p, C.c_uint64, C.c_int32, C.c_uint32, C.c_void_p, C.c_int32,
                                         C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cm_mlp_pack_bytes": (C.c_size_t, [C.POINTER(MlpWeights)]),
+    "cm_mlp_pack": (C.c_int, [C.POINTER(MlpWeights), C.c_void_p, C.c_void_p]),
     "cm_mlp_value_forward": (C.c_int, [C.POINTER(MlpWeights), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cm_masked_agg_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -60,4 +60,8 @@ struct cm_env {
 
 namespace cm {
 int check_tape(const cm_env *h, const cm_rng_tape *tape, bool is_reset);   // cm_env.hip: tape pointers the config needs
+namespace mf {
+// cm_policy_mfma.hip: one layer's weights [K,OUT] -> MFMA B fragments [out_pad/16][kpad/16][64 lanes][4], zero padded
+int pack_one(const float *Wt, int K, int OUT, int kpad, int out_pad, float *dst, void *stream);
+}
 }

@@ -29,6 +29,7 @@ struct Args {
     int rows, in_dim, n_layers, tanh_mask, sw;
     int out_dim[MAXL];
     const float *wt[MAXL], *b[MAXL];
+    const float *pk[MAXL];          // per-layer B fragments (cm_mlp_pack) or NULL: [ct][kq][lane][4], kq over ceil(K/16)
     const float *x, *avail;
     int groups, n_act, agents_per_env, env_id_offset, greedy;
     uint32_t key0, key1, policy_step;
@@ -63,6 +64,7 @@ __global__ __launch_bounds__(TPB) void mlp_kernel(Args a) {
     {
         const int K = a.in_dim, OUT = a.out_dim[0];
         const int nct = (OUT + 15) >> 4;                     // <= 8 (host-checked: OUT <= 128)
+        const int KQ0 = (K + 15) >> 4;
         const float *__restrict__ Wt = a.wt[0];
         v4f acc[2][2];
 #pragma unroll
@@ -87,10 +89,15 @@ __global__ __launch_bounds__(TPB) void mlp_kernel(Args a) {
                     if (ct >= nct) continue;                 // wave-uniform
                     const int col = ct * 16 + c;
                     float bw[4];
+                    if (a.pk[0]) {                           // one unconditional 16-byte load per lane
+                        const float4 v = reinterpret_cast<const float4 *>(a.pk[0])[((size_t)ct * KQ0 + (c0 >> 4) + kq) * 64 + lane];
+                        bw[0] = v.x; bw[1] = v.y; bw[2] = v.z; bw[3] = v.w;
+                    } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int k = c0 + 16 * kq + 4 * g + j;
-                        bw[j] = (k < K && col < OUT) ? Wt[(size_t)k * OUT + col] : 0.0f;
+                        for (int j = 0; j < 4; ++j) {
+                            const int k = c0 + 16 * kq + 4 * g + j;
+                            bw[j] = (k < K && col < OUT) ? Wt[(size_t)k * OUT + col] : 0.0f;
+                        }
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -128,10 +135,15 @@ __global__ __launch_bounds__(TPB) void mlp_kernel(Args a) {
                 const float4 a1 = *reinterpret_cast<const float4 *>(in + (size_t)(16 + c) * sw + 16 * kq + 4 * g);
                 const float x0[4] = { a0.x, a0.y, a0.z, a0.w }, x1[4] = { a1.x, a1.y, a1.z, a1.w };
                 float bw[4];
+                if (a.pk[l]) {
+                    const float4 v = reinterpret_cast<const float4 *>(a.pk[l])[((size_t)ct * k16 + kq) * 64 + lane];
+                    bw[0] = v.x; bw[1] = v.y; bw[2] = v.z; bw[3] = v.w;
+                } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int k = 16 * kq + 4 * g + j;
-                    bw[j] = (k < K && col < OUT) ? Wt[(size_t)k * OUT + col] : 0.0f;
+                    for (int j = 0; j < 4; ++j) {
+                        const int k = 16 * kq + 4 * g + j;
+                        bw[j] = (k < K && col < OUT) ? Wt[(size_t)k * OUT + col] : 0.0f;
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -200,6 +212,8 @@ __global__ __launch_bounds__(TPB) void mlp_kernel(Args a) {
     }
 }
 
+static size_t pack_floats(int K, int OUT) { return (size_t)((OUT + 15) >> 4) * ((K + 15) >> 4) * 256; }
+
 static int launch(Args a, void *stream) {
     int maxw = CHUNK;
     for (int l = 0; l < a.n_layers; ++l) maxw = max(maxw, (a.out_dim[l] + 15) & ~15);
@@ -230,6 +244,11 @@ static int fill(Args &a, const cm_mlp_weights *w, int32_t rows, const float *x) 
         if (w->out_dim[l] < 1 || w->out_dim[l] > 1024) return set_error(CM_ERR_ARG, "mlp forward: layer width outside 1..1024");
         if (!w->wt[l]) return set_error(CM_ERR_ARG, "mlp forward: null layer weight");
         a.out_dim[l] = w->out_dim[l]; a.wt[l] = w->wt[l]; a.b[l] = w->b[l];
+    }
+    size_t off = 0;
+    for (int l = 0; l < w->n_layers; ++l) {
+        a.pk[l] = w->mfma_pack ? w->mfma_pack + off : nullptr;
+        off += pack_floats(l == 0 ? w->in_dim : w->out_dim[l - 1], w->out_dim[l]);
     }
     return CM_OK;
 }
@@ -263,6 +282,27 @@ int cm_mlp_value_forward(const cm_mlp_weights *w, int32_t rows, const float *x, 
     if (w->out_dim[w->n_layers - 1] != 1) return cm::set_error(CM_ERR_ARG, "mlp value forward: last layer width != 1");
     a.values = values;
     return cm::mlp::launch(a, stream);
+}
+
+size_t cm_mlp_pack_bytes(const cm_mlp_weights *w) {
+    if (!w || w->n_layers < 1 || w->n_layers > cm::mlp::MAXL || w->in_dim < 1) return 0;
+    size_t n = 0;
+    for (int l = 0; l < w->n_layers; ++l) {
+        if (w->out_dim[l] < 1) return 0;
+        n += cm::mlp::pack_floats(l == 0 ? w->in_dim : w->out_dim[l - 1], w->out_dim[l]);
+    }
+    return n * sizeof(float);
+}
+
+int cm_mlp_pack(const cm_mlp_weights *w, float *pack, void *stream) {
+    if (!w || !pack || !cm_mlp_pack_bytes(w)) return cm::set_error(CM_ERR_ARG, "cm_mlp_pack: null / malformed argument");
+    size_t off = 0;
+    for (int l = 0; l < w->n_layers; ++l) {
+        const int K = l == 0 ? w->in_dim : w->out_dim[l - 1], OUT = w->out_dim[l];
+        if (int rc = cm::mf::pack_one(w->wt[l], K, OUT, (K + 15) & ~15, (OUT + 15) & ~15, pack + off, stream)) return rc;
+        off += cm::mlp::pack_floats(K, OUT);
+    }
+    return CM_OK;
 }
 
 }  // extern "C"

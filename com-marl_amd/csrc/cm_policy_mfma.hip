@@ -123,7 +123,7 @@ __global__ void pack_layer_kernel(const float *__restrict__ Wt, int K, int OUT, 
 
 
 
-static int pack_one(const float *Wt, int K, int OUT, int kpad, int out_pad, float *dst, void *stream) {
+int pack_one(const float *Wt, int K, int OUT, int kpad, int out_pad, float *dst, void *stream) {
     if (!Wt) return set_error(CM_ERR_ARG, "weight pack: null layer weight");
     const int KQ = kpad / 16, CT = out_pad / 16, total = CT * KQ * 256;
     hipLaunchKernelGGL(pack_layer_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, Wt, K, OUT, KQ, CT, dst);

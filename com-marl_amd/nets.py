@@ -658,11 +658,28 @@ class _RowMLPPolicy(_WeightPack):
             t[f"b{i}"] = lin.bias
         return t
 
+    _mlp_pack = None
+
+    def _after_pack(self, ptrs):
+        """(Re)build the B-fragment pack of the chain (cm_mlp_pack) in a persistent buffer."""
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            return
+        w = self._struct_from(ptrs)
+        if self._mlp_pack is None or self._mlp_pack.device != dev:
+            self._mlp_pack = torch.zeros(L.lib().cm_mlp_pack_bytes(C.byref(w)) // 4, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            L.check(L.lib().cm_mlp_pack(C.byref(w), L.ptr(self._mlp_pack), L.current_stream()), "cm_mlp_pack")
+
     def _mlp_struct(self):
+        w = self._struct_from(self._packed())
+        w.mfma_pack = None if self._mlp_pack is None else self._mlp_pack.data_ptr()
+        return w
+
+    def _struct_from(self, p):
         chain = self._chain()
         if len(chain) > L.MLP_MAX_LAYERS:
             raise L.CommarlError(f"fused MLP forward takes at most {L.MLP_MAX_LAYERS} linear layers")
-        p = self._packed()
         w = L.MlpWeights()
         w.in_dim, w.n_layers, w.tanh_mask = chain[0][0].in_features, len(chain), 0
         for i, (lin, th) in enumerate(chain):
@@ -816,6 +833,9 @@ class GaussianMLPBaseline(_WeightPack, nn.Module):
 
     _pack_tensors = _RowMLPPolicy._pack_tensors
     _mlp_struct = _RowMLPPolicy._mlp_struct
+    _struct_from = _RowMLPPolicy._struct_from
+    _after_pack = _RowMLPPolicy._after_pack
+    _mlp_pack = None
 
     @torch.no_grad()
     def values_device(self, obs):

@@ -232,7 +232,11 @@ typedef struct cm_mlp_weights {
     int32_t tanh_mask, _pad;
     const float *wt[CM_MLP_MAX_LAYERS];
     const float *b[CM_MLP_MAX_LAYERS];   /* NULL = no bias */
+    const float *mfma_pack;              /* cm_mlp_pack() output (all layers, B fragments as in cm_policy_pack), or NULL:
+                                            the kernel then gathers the plain weights (slower) */
 } cm_mlp_weights;
+size_t cm_mlp_pack_bytes(const cm_mlp_weights *w);
+int cm_mlp_pack(const cm_mlp_weights *w, float *pack, void *stream);
 
 /* DecCategoricalMLPPolicy.get_actions (com_marl/torch/policies/dec_categorical_mlp_policy.py:106-176; encoder 2
  * layers + head 2 layers = one 4-layer chain per AGENT row: rows = S*N, groups = 1) and

@@ -37,7 +37,7 @@ def test_struct_layouts_match_header_sizes():
     assert C.sizeof(_lib.EnvState) == 9 * 8
     assert C.sizeof(_lib.PolicyWeights) == 10 * 4 + 16 * 8
     assert C.sizeof(_lib.CriticWeights) == 8 * 4 + 12 * 8
-    assert C.sizeof(_lib.MlpWeights) == 2 * 4 + 6 * 4 + 2 * 4 + 12 * 8
+    assert C.sizeof(_lib.MlpWeights) == 2 * 4 + 6 * 4 + 2 * 4 + 13 * 8
 
 
 def test_argument_errors_without_gpu():
