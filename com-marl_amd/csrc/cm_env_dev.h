@@ -258,15 +258,27 @@ __device__ __forceinline__ void emit(const EnvDev &p, const Lds l, const Rng rng
             }
         } else {
             const uint32_t site = slot ? SITE_IID_RESET : SITE_IID_STEP;
+            // one Philox call = 4 consecutive links.  The diagonal (i == j <=> ij is a multiple of N + 1) is found with one
+            // exact float division per element, and when L*N*N is a multiple of 4 (every env's block is then 16-byte
+            // aligned) the four masks leave as one 16-byte store
+            const float rcp_N1 = 1.0f / (float)(N + 1);
+            const bool vec = (total & 3) == 0;
             for (int q = sl; q * 4 < total; q += LPE) {
                 const u32x4 x = rng.at(site, (uint32_t)q);
+                const int hop = fdiv(q * 4, NN, rcp_NN);
+                float m[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int k = q * 4 + e;
-                    if (k < total) {
-                        const int ij = k - fdiv(k, NN, rcp_NN) * NN, i = fdiv(ij, N, rcp_N), j = ij - i * N;
-                        ch[k] = ((unit_f32(pick(x, e)) + (i == j ? 1.0f : 0.0f)) >= p.ploss) ? 1.0f : 0.0f;
-                    }
+                    int ij = k - hop * NN;
+                    if (ij >= NN) ij -= NN;                            // the 4 links may straddle a hop boundary
+                    const bool diag = fdiv(ij, N + 1, rcp_N1) * (N + 1) == ij;
+                    m[e] = ((unit_f32(pick(x, e)) + (diag ? 1.0f : 0.0f)) >= p.ploss) ? 1.0f : 0.0f;
+                }
+                if (vec) *reinterpret_cast<float4 *>(ch + q * 4) = make_float4(m[0], m[1], m[2], m[3]);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (q * 4 + e < total) ch[q * 4 + e] = m[e];
                 }
             }
         }
