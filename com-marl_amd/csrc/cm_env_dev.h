@@ -9,6 +9,7 @@ namespace cm {
 
 constexpr int C_EMPTY = 0, C_AGENT = 1, C_PREY = 2, C_WALL = 3;
 constexpr int WAVE = 64;
+constexpr int PAR_AGENTS_MIN = 16;  // teams larger than this resolve their moves in parallel rounds (agents_parallel)
 
 // Every LDS hand-off in the env code is between lanes of ONE wave (an env's group never spans waves), and a wave's LDS
 // operations execute in issue order: draining the LDS counter is all the synchronisation needed.  (A workgroup barrier
@@ -36,6 +37,7 @@ struct Lds {           // byte offsets into smem (kept in registers: always pass
     int pcnt;          // [M] u8 predator count around prey j
     int pmv;           // [M] u8 chosen prey move | 8 = tape ran out
     int vis;           // [S] u32
+    int own, win, st;  // parallel agent resolution: [S*S] u8 owner index + 1, [S*S] u32 lowest contender, [N] u8 status
 #ifdef CM_BOUNDS
     int nS2, nN, nM, nS;
     int32_t *status;
@@ -47,6 +49,7 @@ __host__ __device__ inline int lds_env_bytes(int S, int N, int M) {
     int off = 0;
     lds_take(off, S * S); lds_take(off, 2 * N); lds_take(off, 2 * N); lds_take(off, 2 * M); lds_take(off, 2 * M);
     lds_take(off, N); lds_take(off, M); lds_take(off, M); lds_take(off, M); lds_take(off, 4 * S);
+    lds_take(off, S * S); lds_take(off, 4 * S * S); lds_take(off, N);
     return off;
 }
 __device__ __forceinline__ Lds make_lds(int S, int N, int M, int base, int32_t *status) {
@@ -55,6 +58,7 @@ __device__ __forceinline__ Lds make_lds(int S, int N, int M, int base, int32_t *
     l.g = lds_take(off, S * S); l.ar = lds_take(off, 2 * N); l.ac = lds_take(off, 2 * N); l.pr = lds_take(off, 2 * M);
     l.pc = lds_take(off, 2 * M); l.act = lds_take(off, N); l.alive = lds_take(off, M); l.pcnt = lds_take(off, M);
     l.pmv = lds_take(off, M); l.vis = lds_take(off, 4 * S);
+    l.own = lds_take(off, S * S); l.win = lds_take(off, 4 * S * S); l.st = lds_take(off, N);
 #ifdef CM_BOUNDS
     l.nS2 = S * S; l.nN = N; l.nM = M; l.nS = S; l.status = status;
 #endif
@@ -82,6 +86,9 @@ __device__ __forceinline__ uint8_t &ACT(const Lds l, int i) { return smem[l.act 
 __device__ __forceinline__ uint8_t &ALV(const Lds l, int i) { return smem[l.alive + chk(l, i, nM, 7)]; }
 __device__ __forceinline__ uint8_t &PCNT(const Lds l, int i) { return smem[l.pcnt + chk(l, i, nM, 8)]; }
 __device__ __forceinline__ uint8_t &PMV(const Lds l, int i) { return smem[l.pmv + chk(l, i, nM, 9)]; }
+__device__ __forceinline__ uint8_t &OWN(const Lds l, int i) { return smem[l.own + chk(l, i, nS2, 12)]; }
+__device__ __forceinline__ uint32_t &WIN(const Lds l, int i) { return reinterpret_cast<uint32_t *>(smem + l.win)[chk(l, i, nS2, 13)]; }
+__device__ __forceinline__ uint8_t &ST(const Lds l, int i) { return smem[l.st + chk(l, i, nN, 14)]; }
 __device__ __forceinline__ uint32_t &VIS(const Lds l, int i) { return reinterpret_cast<uint32_t *>(smem + l.vis)[chk(l, i, nS, 10)]; }
 
 // Branch-free probes: the address is clamped into the tile and the result masked by the bounds test, so the
@@ -352,6 +359,107 @@ __device__ __forceinline__ void emit(const EnvDev &p, const Lds l, const Rng rng
 // ---------------------------------------------------------------------------------------
 // the step kernel
 // ---------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------
+// Agent moves of one step for large teams, resolved in parallel instead of N sequential iterations.
+// Reference semantics (predator_prey.py:497-500 / coverage.py:330-365): agents act in index order; agent i moves
+// iff its target cell is inside the grid and empty AT ITS TURN (neither wall, live prey, nor any agent - agents < i
+// at their new cells, agents > i at their old ones).  Hence for a target cell X that is no wall / prey:
+//   * X is the start cell of agent j > i            -> i stays (j has not moved yet);
+//   * several agents target X                        -> only the lowest index among those not excluded above can
+//                                                      ever enter it (if it cannot, X stays occupied for the others);
+//   * that lowest contender i moves iff X was empty at the start, or its owner j < i moved away.
+// The only dependencies are on LOWER indices (owner of the target), so a few rounds of "look up my owner's
+// outcome" settle everything; chains are as long as a queue of agents walking behind each other.
+// Leaves positions and the occupancy tile updated; returns the per-step counters.
+// ---------------------------------------------------------------------------------------
+struct MoveOut { int moving, lazy, cap, rev, pen; };
+
+template <int SCEN, int LPE>
+__device__ __forceinline__ MoveOut agents_parallel(const EnvDev &p, const Lds l, const Grp<LPE> g) {
+    constexpr int MAXA = 256 / LPE;                     // agents per lane (n_agents <= 255)
+    const int S = p.S, N = p.N, sl = g.sl;
+    MoveOut mo{ 0, 0, 0, 0, 0 };
+    for (int k = sl; k < S * S; k += LPE) { OWN(l, k) = 0; WIN(l, k) = 0xFFFFFFFFu; }
+    ENV_SYNC();
+    int act[MAXA], r0[MAXA], c0[MAXA], tgt[MAXA], own[MAXA], st[MAXA];     // st: 0 stay, 1 moved, 2 pending on own[]
+#pragma unroll
+    for (int q = 0; q < MAXA; ++q) {
+        const int i = sl + q * LPE;
+        act[q] = 4; r0[q] = c0[q] = 0; tgt[q] = -1; own[q] = -1; st[q] = 0;
+        if (i < N) { act[q] = ACT(l, i); r0[q] = AR(l, i); c0[q] = AC(l, i); OWN(l, r0[q] * S + c0[q]) = (uint8_t)(i + 1); }
+    }
+    ENV_SYNC();
+#pragma unroll
+    for (int q = 0; q < MAXA; ++q) {
+        const int i = sl + q * LPE;
+        if (i < N && act[q] != 4) {
+            const int nr = r0[q] + dr_of(act[q]), nc = c0[q] + dc_of(act[q]);
+            if (in_grid(nr, nc, S)) {
+                const int X = nr * S + nc, cellv = Gc(l, X);
+                if (cellv == C_EMPTY || cellv == C_AGENT) {
+                    const int j = (int)OWN(l, X) - 1;                     // -1: empty at the start of the step
+                    if (j < i) { tgt[q] = X; own[q] = j; atomicMin(&WIN(l, X), (uint32_t)i); }
+                }
+            }
+        }
+    }
+    ENV_SYNC();
+    bool pend = false;
+#pragma unroll
+    for (int q = 0; q < MAXA; ++q) {
+        const int i = sl + q * LPE;
+        if (tgt[q] >= 0) {
+            if (WIN(l, tgt[q]) != (uint32_t)i) tgt[q] = -1;               // a lower index owns the claim on this cell
+            else st[q] = own[q] < 0 ? 1 : 2;
+        }
+        if (i < N) ST(l, i) = (uint8_t)st[q];
+        pend |= st[q] == 2;
+    }
+    ENV_SYNC();
+    while (g.any(pend)) {                               // follow the owner chains (lower indices settle first)
+        pend = false;
+#pragma unroll
+        for (int q = 0; q < MAXA; ++q) {
+            if (st[q] == 2) {
+                const int sj = ST(l, own[q]);
+                if (sj != 2) { st[q] = sj; ST(l, sl + q * LPE) = (uint8_t)sj; }
+                pend |= st[q] == 2;
+            }
+        }
+        ENV_SYNC();
+    }
+    // counters + the visited test against the start-of-step bitmap (a cell entered this step is occupied, so nobody
+    // else can "see" it visited or unvisited afterwards)
+    bool seen[MAXA];
+#pragma unroll
+    for (int q = 0; q < MAXA; ++q) {
+        const int i = sl + q * LPE;
+        const bool is = i < N, moved = st[q] == 1;
+        seen[q] = false;
+        if (SCEN == CM_CO && moved) { const int X = tgt[q], nr = fdiv(X, S, 1.0f / (float)S); seen[q] = (VIS(l, nr) >> (X - nr * S)) & 1u; }
+        mo.moving += g.count(is && act[q] != 4);
+        mo.lazy += g.count(is && act[q] == 4);
+        mo.pen += g.count(is && act[q] != 4 && !moved);
+        mo.cap += g.count(moved && !seen[q]);
+        mo.rev += g.count(moved && seen[q]);
+    }
+    ENV_SYNC();
+#pragma unroll
+    for (int q = 0; q < MAXA; ++q) if (st[q] == 1) Gc(l, r0[q] * S + c0[q]) = C_EMPTY;       // leave ...
+    ENV_SYNC();
+#pragma unroll
+    for (int q = 0; q < MAXA; ++q) {
+        if (st[q] == 1) {                                                                    // ... then enter
+            const int X = tgt[q], nr = fdiv(X, S, 1.0f / (float)S), nc = X - nr * S;
+            Gc(l, X) = C_AGENT;
+            AR(l, sl + q * LPE) = (int16_t)nr; AC(l, sl + q * LPE) = (int16_t)nc;
+            if (SCEN == CM_CO) atomicOr(&VIS(l, nr), 1u << nc);
+        }
+    }
+    ENV_SYNC();
+    return mo;
+}
+
 // One env per LPE-lane group.  `grp` = group index inside the workgroup (LDS slot), `b_raw` = env index (groups with
 // b_raw >= p.B or !grp_live shadow the last env and never commit), `lds_base` = byte offset of the env area in the
 // dynamic LDS block, `act_lds` = optional [N] action bytes already in LDS for this env (fused rollout kernel), else
@@ -418,9 +526,10 @@ __device__ __forceinline__ void env_body(const EnvDev &p, const int32_t *__restr
     int det0 = 0, det1 = 0, det2 = 0, det3 = 0, det4 = 0, det5 = 0;
 
     if (SCEN == CM_PP) {
-        // ---- agents move in index order (predator_prey.py:497-500, :240-261): group-uniform loop ----
+        // ---- agents move in index order (predator_prey.py:497-500, :240-261) ----
         int moving = 0;
-        for (int i = 0; i < N; ++i) {
+        if (N > PAR_AGENTS_MIN) moving = agents_parallel<SCEN, LPE>(p, l, g).moving;      // large teams: parallel resolution
+        else for (int i = 0; i < N; ++i) {                                                // small teams: group-uniform loop
             const int a = ACT(l, i);
             bool mv = false;
             int r = 0, c = 0, nr = 0, nc = 0;
@@ -521,7 +630,10 @@ __device__ __forceinline__ void env_body(const EnvDev &p, const int32_t *__restr
     } else {
         // ---- Coverage.step (:319-378): sequential agents against tile + visited bitmap ----
         int cap = 0, mov = 0, pen = 0, lazy = 0, rev = 0;
-        for (int i = 0; i < N; ++i) {
+        if (N > PAR_AGENTS_MIN) {
+            const MoveOut mo = agents_parallel<SCEN, LPE>(p, l, g);
+            cap = mo.cap; mov = mo.moving; pen = mo.pen; lazy = mo.lazy; rev = mo.rev;
+        } else for (int i = 0; i < N; ++i) {
             const int a = ACT(l, i);
             bool mv = false, seen = false;
             int r = 0, c = 0, nr = 0, nc = 0;
