@@ -99,7 +99,8 @@ static int dispatch(const FwdArgs &a, const TrunkW &tw, const PolHead &ph, const
     // large teams run 8-wave workgroups (one workgroup per CU fits in LDS: two waves per SIMD hide each other's
     // latencies); COMMARL_FWD_WAVES=4 selects the 4-wave build of the same code for A/B timing
     static const bool w8_on = [] { const char *e = getenv("COMMARL_FWD_WAVES"); return !(e && e[0] == '4'); }();
-    const bool w8 = w8_on && a.N >= 32;   // measured: N = 54 245 -> 178 us, N = 72 280 -> 213 us; N = 24 (48 rows) is faster on 4 waves
+    static const int w8_min = [] { const char *e = getenv("COMMARL_FWD_W8MIN"); return e ? atoi(e) : 32; }();
+    const bool w8 = w8_on && a.N >= w8_min;   // measured: N = 54 245 -> 178 us, N = 72 280 -> 213 us; N = 24 (48 rows) is faster on 4 waves
 #define CM_FWD(K) (quad ? launch<HEAD, K, -1>(a, tw, ph, chd, stream) : mk == 0 ? launch<HEAD, K, 0>(a, tw, ph, chd, stream) \
                    : mk == 25 ? (w8 ? launch<HEAD, K, 15, 8>(a, tw, ph, chd, stream) : launch<HEAD, K, 25>(a, tw, ph, chd, stream)) \
                               : (w8 ? launch<HEAD, K, 32, 8>(a, tw, ph, chd, stream) : launch<HEAD, K, 64>(a, tw, ph, chd, stream)))

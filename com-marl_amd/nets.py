@@ -740,6 +740,11 @@ class _RowMLPPolicy(_WeightPack):
             return Categorical(probs=probs.reshape(*obs_n.shape[:-1], self._n_agents, -1).cpu())
         return Categorical(probs=self._probs(obs_n, avail_actions_n)[0])
 
+    @staticmethod
+    def _need_gpu(x):
+        if not x.is_cuda:
+            raise L.CommarlError("policy tensors must live on the MI355X (device cuda:k); there is no CPU path")
+
     def _masked(self, logits, avail_actions_n):
         probs = torch.softmax(logits, dim=-1)
         if avail_actions_n is not None:
@@ -781,6 +786,7 @@ class DecCategoricalMLPPolicy(_RowMLPPolicy, MLPModule):
                 + [(l.linear, True) for l in self._layers] + [(self._output_layers[0].linear, False)])
 
     def _probs(self, obs_n, avail_actions_n, dist_adj=None, channels=None):
+        self._need_gpu(obs_n)
         obs = obs_n.reshape(obs_n.shape[:-1] + (self._n_agents, -1))              # :110
         logits = MLPModule.forward(self, self.encoder(obs))
         return self._masked(logits, avail_actions_n), None
@@ -806,6 +812,7 @@ class CentralizedCategoricalMLPPolicy(_RowMLPPolicy, MLPModule):
         return [(l.linear, True) for l in self._layers] + [(self._output_layers[0].linear, False)]
 
     def _probs(self, obs_n, avail_actions_n, dist_adj=None, channels=None):
+        self._need_gpu(obs_n)
         logits = MLPModule.forward(self, obs_n)
         logits = logits.reshape(logits.shape[:-1] + (self._n_agents, -1))         # :83
         return self._masked(logits, avail_actions_n), None
@@ -860,5 +867,6 @@ class GaussianMLPBaseline(_WeightPack, nn.Module):
         return self.module(obs)[0].flatten(-2)
 
     def compute_loss(self, obs, returns):
+        _RowMLPPolicy._need_gpu(obs)
         mean, std = self.module(obs.reshape(-1, self.input_dim))                  # :93-96
         return -Normal(mean, std).log_prob(returns.reshape(-1, 1)).mean()
