@@ -331,6 +331,8 @@ class CommBaseNet(_WeightPack, nn.Module):
 
     def trunk(self, obs, adj, ch):
         """obs [S,N,d] -> (E, H_L, M) with autograd (CommBaseNet.forward :80-108)."""
+        if not obs.is_cuda:
+            raise L.CommarlError("policy / critic tensors must live on the MI355X (device cuda:k); there is no CPU path")
         E = self.encoder(obs)
         M = self.attention_layer(E)
         H = E
