@@ -543,6 +543,80 @@ __device__ __forceinline__ void env_body(const EnvDev &p, const int32_t *__restr
             ENV_SYNC();
         }
         if (p.stop == 3) return;
+        int capture = 0, penalty = 0, wsum = 0;
+        bool tape_short = false;
+        if (LPE == 64) {
+        // ---- one wave per env: the per-prey inputs of the sequential loop (alive, position, predator count, chosen
+        // move - all start-of-phase values, nothing an earlier prey can change) stay in the registers of the lane that
+        // computed them; iteration j fetches them with v_readlane (no LDS round trip) and issues its five tile probes
+        // together, so an iteration is ONE LDS latency instead of four dependent ones ----
+        constexpr int MAXP = 4;                              // n_preys <= 255
+        int pk[MAXP];                                        // alive | r << 1 | c << 7 | cnt << 13 | move(+8) << 17
+#pragma unroll
+        for (int q = 0; q < MAXP; ++q) {
+            const int j = sl + q * LPE;
+            int cnt = 0, mv = 4, alive = 0, r = 0, c = 0;
+            if (j < M && ALV(l, j)) {
+                alive = 1; r = PR(l, j); c = PC(l, j);
+                cnt = count_adj(l, r, c, S, C_AGENT);
+                const bool captured_now = (p.load == 2) && cnt >= 1 && p.load <= cnt;
+                if (!captured_now) {                          // prey_random_move (:396-407)
+                    bool found = false;
+                    u32x4 x = { 0, 0, 0, 0 };
+                    for (int t = 0; t < 5 && !found; ++t) {
+                        int m;
+                        if (p.rng_mode == CM_RNG_TAPE) {
+                            m = tape.prey[((size_t)b * M + j) * 5 + t];
+                            if (m > 4) { mv = 4 | 8; break; }
+                        } else {
+                            if ((t & 3) == 0) x = rng.at(SITE_PREY, (uint32_t)(2 * j + (t >> 2)));
+                            m = prey_move_from_u32(pick(x, t & 3));
+                        }
+                        if (count_adj(l, r + dr_of(m), c + dc_of(m), S, C_AGENT) == 0) { mv = m; found = true; }
+                    }
+                }
+            }
+            pk[q] = alive | (r << 1) | (c << 7) | (cnt << 13) | (mv << 17);
+        }
+        for (int i0 = 0; i0 < N; i0 += LPE) {                 // prey_watching (:419-423)
+            const int i = i0 + sl;
+            const bool w = i < N && count_adj(l, AR(l, i), AC(l, i), S, C_PREY) > 0;
+            wsum += g.count(w);
+        }
+        ENV_SYNC();
+        if (p.stop == 4) return;
+        for (int j = 0; j < M; ++j) {
+            const int lanej = j & (LPE - 1), qj = j >> 6;
+            const int v0 = __builtin_amdgcn_readlane(pk[0], lanej), v1 = __builtin_amdgcn_readlane(pk[1], lanej),
+                      v2 = __builtin_amdgcn_readlane(pk[2], lanej), v3 = __builtin_amdgcn_readlane(pk[3], lanej);
+            const int v = qj == 0 ? v0 : (qj == 1 ? v1 : (qj == 2 ? v2 : v3));
+            if (!(v & 1)) continue;                            // dead before this step (uniform)
+            const int r = (v >> 1) & 63, c = (v >> 7) & 63, cnt = (v >> 13) & 15, mvb = (v >> 17) & 15, mv = mvb & 7;
+            const int nr = r + dr_of(mv), nc = c + dc_of(mv);
+            const int npre = count_adj(l, r, c, S, C_PREY);                     // 4 probes + the target probe: one round trip
+            const int tcell = cell(l, nr, nc, S);
+            bool captured = false, moved = false;
+            if (cnt >= 1) {
+                int need = p.load;
+                if (p.load != 2) {                                               // reward_individual :467-470
+                    const bool on_r = (r == 0 || r == S - 1), on_c = (c == 0 || c == S - 1);
+                    const int adj = (on_r && on_c) ? 2 : ((on_r || on_c) ? 3 : p.load);   // __create_edges :123-144
+                    const int avail = adj - npre;
+                    need = p.load < avail ? p.load : avail;
+                }
+                if (need <= cnt) { captured = true; ++capture; } else ++penalty;
+            }
+            if (!captured) {
+                if (mvb & 8) tape_short = true;
+                moved = mv != 4 && tcell == C_EMPTY;                             // cell() is -1 outside the grid
+            }
+            if (sl == 0) {
+                if (captured) { ALV(l, j) = 0; Gc(l, r * S + c) = C_EMPTY; }      // :301
+                else if (moved) { Gc(l, r * S + c) = C_EMPTY; Gc(l, nr * S + nc) = C_PREY; PR(l, j) = (int16_t)nr; PC(l, j) = (int16_t)nc; }
+            }
+            ENV_SYNC();
+        }
+        } else {
         // ---- per-prey work that only depends on the (now static) agent layer: one lane per prey ----
         for (int j = sl; j < M; j += LPE) {
             int cnt = 0, mv = 4;
@@ -570,7 +644,6 @@ __device__ __forceinline__ void env_body(const EnvDev &p, const int32_t *__restr
             PCNT(l, j) = (uint8_t)cnt; PMV(l, j) = (uint8_t)mv;
         }
         // prey_watching (:419-423): agents 4-adjacent to a live prey (prey layer still at start-of-phase positions)
-        int wsum = 0;
         for (int i0 = 0; i0 < N; i0 += LPE) {
             const int i = i0 + sl;
             const bool w = i < N && count_adj(l, AR(l, i), AC(l, i), S, C_PREY) > 0;
@@ -579,8 +652,6 @@ __device__ __forceinline__ void env_body(const EnvDev &p, const int32_t *__restr
         ENV_SYNC();
         if (p.stop == 4) return;
         // ---- captures + prey moves in index order (:416-432 / :460-478, :276-301): group-uniform loop ----
-        int capture = 0, penalty = 0;
-        bool tape_short = false;
         for (int j = 0; j < M; ++j) {
             const bool alive = ALV(l, j) != 0;
             bool captured = false, moved = false;
@@ -614,6 +685,7 @@ __device__ __forceinline__ void env_body(const EnvDev &p, const int32_t *__restr
             }
             ENV_SYNC();
         }
+        }   // LPE != 64
         if (p.stop == 5) return;
         if (tape_short && sl == 0 && commit) raise(p, CM_ERR_TAPE_PREY);
         // reward in f64 exactly as the Python expression evaluates (:434 / :480); no FMA contraction (build flag)
