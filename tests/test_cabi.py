@@ -82,3 +82,17 @@ def test_graft_entry_build_runs():
     """The driver's build check: compiles (no-op when up to date), imports the package, resolves every symbol."""
     import __graft_entry__ as g
     g.build()
+
+
+def test_bench_contract_helpers():
+    """bench.py imports on a machine without a GPU and its byte / FLOP accounting matches SURVEY.md §8(d)."""
+    import bench
+    assert set(bench.CONFIGS) == {"pp_map10", "co_map20", "pp_map30", "co_map30"}
+    c = bench.CONFIGS["pp_map10"]
+    b_env, b_pol = bench.algorithmic_bytes(c, 21, adj_const=True, ch_const=True)
+    assert (b_env, b_pol, b_env + b_pol) == (501, 496, 997)                 # config 2: 997 B per env-step
+    c4 = bench.CONFIGS["pp_map30"]
+    b_env, b_pol = bench.algorithmic_bytes(c4, 53, adj_const=False, ch_const=True)
+    assert abs((b_env + b_pol) - 97.2e3) < 0.5e3                            # config 4: ~97.2 KB
+    assert bench.policy_flops(c, 21) == 340224                              # 2N(128d + 39 621 + 192N) at d=21, N=4
+    assert bench.host_cores() >= 1
