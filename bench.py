@@ -166,7 +166,23 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--policy", default="commdp", choices=["commdp", "obsdp", "cent"],
                     help="Comm-DP GNN policy (the headline) or the reference's Obs-DP / CENT variants (SURVEY.md §8f-2)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: the config's env batch on EVERY GPU (default); strong: the batch split over the GPUs "
+                         "(SURVEY.md §8e: 4096 -> 4096/2048/1024/512 envs per GPU)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start N fresh ranks (one per GPU) and relay rank 0's line.
+        # Nothing in this process has touched the GPU yet, and the ranks are children, never a re-exec.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
     import numpy as np
     import torch
@@ -175,6 +191,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs the MI355X; there is no CPU path")
     # one rank per GPU; COMMARL_DIST_BACKEND=gloo lets several ranks share one GPU to rehearse the N>1 path
@@ -194,6 +213,10 @@ def main():
 
     c = dict(CONFIGS[args.config])
     B = args.envs or c["envs"]
+    if args.scaling == "strong":                        # the batch is split: rank r owns global envs [r*B/k, (r+1)*B/k)
+        if B % world:
+            raise SystemExit(f"--scaling strong: {B} envs do not split over {world} GPUs")
+        B //= world
     c["envs"] = B
     env = E.GridEnvBatch(c["scenario"], env_params(c), B, device=dev, seed=args.seed, env_id_offset=rank * B)
     n_streams = args.streams if args.streams is not None else c.get("streams", 2)
@@ -207,38 +230,48 @@ def main():
     torch.manual_seed(args.seed)                       # replicas: identical weights on every rank
     policy = make_policy(args.policy, spec, env.N, dev)
     policy.set_rng(args.seed, env_id_offset=rank * B)
-    G = max(1, min(args.chunk, args.steps))
+    # steps per captured hipGraph: --chunk, but never more than a quarter of the timed steps - a graph launch submits
+    # all of its ~4 x G kernel nodes before the first one starts (~9 us of host time per step), which a short timed
+    # region would see as dead time in front of its only replay; with >= 4 replays the later ones are enqueued while
+    # the first executes
+    G = max(1, min(args.chunk, -(-args.steps // 4)))
     eng = RolloutEngine(shards, policy, horizon=G)
     eng.reset()
+    use_graph = not args.no_graph
 
     def barrier():
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
 
-    def run(n):
+    def plan(n):
+        """n steps as chunk lengths: whole chunks of G, then one shorter chunk (its own graph) for the remainder."""
         full, rest = divmod(n, G)
-        for _ in range(full):
-            eng.run_chunk(use_graph=not args.no_graph)
-        if rest:
-            eng.fork()
-        for t in range(rest):                          # remainder steps outside the captured chunk
-            eng.step(t)
-            if t == rest - 1:
-                eng.join()
-                eng.obs[0].copy_(eng.obs[rest])
-                if eng.dist_adj is not None:
-                    eng.dist_adj[0].copy_(eng.dist_adj[rest])
-                if eng.channels is not None:
-                    eng.channels[0].copy_(eng.channels[rest])
+        return [G] * full + ([rest] if rest else [])
 
+    def run(n):
+        for k in plan(n):
+            eng.run_chunk(use_graph=use_graph, n=k)
+
+    # Every graph the timed region replays is captured, instantiated AND replayed once before t0 (capture does not
+    # advance the rollout; the warm-up below is W steps through the same chunk machinery, plus one replay of any
+    # timed-region graph length the W steps did not already use).
+    timed_lengths = sorted(set(plan(args.steps)))
+    if use_graph:
+        for k in timed_lengths:
+            eng.prepare_graph(k)
     run(args.warmup)
+    extra_warm = [k for k in timed_lengths if k not in set(plan(args.warmup))]
+    for k in extra_warm:
+        eng.run_chunk(use_graph=use_graph, n=k)
+    n_captured = len(eng._graphs)
     eng.env.check_status()
     barrier()
     t0 = time.perf_counter()
     run(args.steps)
     barrier()
     dt = time.perf_counter() - t0
+    assert len(eng._graphs) == n_captured, "a hipGraph was captured inside the timed region"
     eng.env.check_status()
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -306,7 +339,7 @@ def main():
                    if (args.config == "pp_map10" and args.policy == "commdp")
                    else f"env-steps/sec (whole node), {args.config}, {args.policy} policy"),
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": (c["label"] if args.policy == "commdp" else c["label"].replace(
             "Comm-DP GNN policy", {"obsdp": "Obs-DP policy (per-agent MLP, no communication)",
@@ -314,6 +347,9 @@ def main():
                                + "; one step = fused policy forward + sample + env step with auto-reset, "
                                "trajectory written to HBM", "envs_per_gpu": B, "total_envs": B * world, "n_agents": c["n_agents"],
                    "obs_dim": env.d, "graph_chunk": 0 if args.no_graph else G, "streams": ns,
+                   "graphs": {"count": n_captured, "chunk_lengths": timed_lengths if use_graph else [],
+                              "capture_in_timed_region": False,
+                              "warmup_steps_run": args.warmup + sum(extra_warm)},
                    "parallelism": f"env-sharded x{world} (no data-path collective in the rollout)"},
         "roofline": roofline,
     }

@@ -344,7 +344,8 @@ class CentralizedMAPPO:
                           dLoss=loss_before - loss_after, KLBefore=kl_before, KL=kl, Entropy=entropy,
                           GradNorm=float(np.mean(grad_norm)) if grad_norm else 0.0, EpochTime=epoch_time,
                           TrainOnceTime=time.time() - t_start, MaxPathLength=T,
-                          EnvSteps=int(valids.sum().item()))
+                          EnvSteps=int(valids.sum().item()),
+                          GPUMemoryMax=torch.cuda.max_memory_allocated(self._dev()) / 1024 ** 3)     # :372-383 (GiB)
         for k, v in self.stats.items():
             tabular.record(k, v)
         return avg_return

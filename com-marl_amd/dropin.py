@@ -15,8 +15,73 @@ reference: experiment runner, logging, snapshotting stay the reference's own).  
 wants the MI355X path puts ``import com_marl_amd.dropin; com_marl_amd.dropin.install()`` before those
 imports and passes ``n_envs`` / ``device`` to the env wrapper.
 """
+import importlib.abc
+import importlib.machinery
 import sys
 import types
+
+
+def _natural_path(name):
+    """Directories the import system would search for sub-modules of package `name` if this package did not stand
+    in for it (the reference's own `com_marl/`, `com_marl/torch/`, `envs/` ... when its tree is on sys.path), found
+    WITHOUT executing anything.  Our stand-in modules carry these as `__path__`, so everything of the reference that
+    is not on the hot path keeps importing from the reference (`com_marl.experiment.local_runner_wrapper`,
+    `com_marl.np.algos`, `envs.ma_gym` ...)."""
+    parent, _, _leaf = name.rpartition(".")
+    try:
+        search = None
+        if parent:
+            pm = sys.modules.get(parent)
+            search = list(getattr(pm, "__path__", [])) if pm is not None else []
+            if not search:
+                return []
+        spec = importlib.machinery.PathFinder.find_spec(name, search)
+        return list(spec.submodule_search_locations or []) if spec is not None else []
+    except Exception:
+        return []
+
+
+def register_base_sampler(base_module=None):
+    """Make the sampler a (virtual) subclass of garage's ``BaseSampler`` so that the reference's runner takes its
+    ``BaseSampler`` branch: ``issubclass(sampler_cls, BaseSampler)`` in LocalRunner.make_sampler
+    (garage/experiment/local_runner.py:181-189) and ``isinstance(self._sampler, BaseSampler)`` in
+    LocalRunnerWrapper.obtain_samples (com_marl/experiment/local_runner_wrapper.py:41-47).  ``BaseSampler`` is an
+    ``abc.ABC`` (garage/sampler/base.py:4,35), so ``register`` is all it takes.  Returns True when registered."""
+    from .sampler import CentralizedMAOnPolicyVectorizedSampler
+    m = base_module or sys.modules.get("garage.sampler.base")
+    base = getattr(m, "BaseSampler", None)
+    if base is None or not hasattr(base, "register"):
+        return False
+    base.register(CentralizedMAOnPolicyVectorizedSampler)
+    return True
+
+
+class _BaseSamplerHook(importlib.abc.MetaPathFinder):
+    """Registers the sampler the moment ``garage.sampler.base`` is imported (install() may run before the runner's
+    garage imports): delegates the lookup to the remaining finders and wraps the loader's exec_module."""
+    TARGET = "garage.sampler.base"
+
+    def find_spec(self, fullname, path=None, target=None):
+        if fullname != self.TARGET:
+            return None
+        for finder in sys.meta_path:
+            if finder is self or not hasattr(finder, "find_spec"):
+                continue
+            spec = finder.find_spec(fullname, path, target)
+            if spec is None or spec.loader is None:
+                continue
+            inner = spec.loader
+
+            class _Loader(importlib.abc.Loader):
+                def create_module(self, spec):
+                    return inner.create_module(spec) if hasattr(inner, "create_module") else None
+
+                def exec_module(self, module):
+                    inner.exec_module(module)
+                    register_base_sampler(module)
+            spec.loader = _Loader()
+            return spec
+        return None
 
 
 def install(force=False):
@@ -26,10 +91,12 @@ def install(force=False):
         if name in sys.modules and not force and not getattr(sys.modules[name], "_commarl_amd", False):
             raise RuntimeError(f"{name} is already imported from elsewhere; call install() before the reference imports "
                                "or pass force=True")
+        path = _natural_path(name)
         m = types.ModuleType(name)
         m.__dict__.update(attrs)
         m._commarl_amd = True
-        m.__path__ = []
+        m.__path__ = path
+        m.__package__ = name
         sys.modules[name] = m
         parent, _, leaf = name.rpartition(".")
         if parent:
@@ -49,8 +116,14 @@ def install(force=False):
         GraphConvolutionModule=nets.GraphConvolutionModule, GaussianMLPModule=nets.GaussianMLPModule)
     mod("com_marl.torch.algos", CentralizedMAPPO=algos.CentralizedMAPPO)
     mod("com_marl.sampler", CentralizedMAOnPolicyVectorizedSampler=sampler.CentralizedMAOnPolicyVectorizedSampler)
-    mod("eval_pp", eval_model=evaluate.eval_model, VECTORS=evaluate.VECTORS)          # exp_runners/predatorprey/eval_pp.py:9
-    mod("eval_co", eval_model=evaluate.eval_model_co, VECTORS=evaluate.VECTORS)       # exp_runners/coverage/eval_co.py:9
+    mod("eval_pp", eval_model=evaluate.eval_model, eval_simple=evaluate.eval_simple,        # exp_runners/predatorprey/
+        VECTORS=evaluate.VECTORS)                                                             # eval_pp.py:9,107
+    mod("eval_co", eval_model=evaluate.eval_model_co, eval_simple=evaluate.eval_simple_co,  # exp_runners/coverage/
+        VECTORS=evaluate.VECTORS)                                                             # eval_co.py:9,104
+    # the runner's BaseSampler gates (local_runner.py:181, local_runner_wrapper.py:41): now if garage is already
+    # imported, otherwise the moment it is
+    if not register_base_sampler() and not any(isinstance(f, _BaseSamplerHook) for f in sys.meta_path):
+        sys.meta_path.insert(0, _BaseSamplerHook())
     return sorted(k for k, v in sys.modules.items() if getattr(v, "_commarl_amd", False))
 
 

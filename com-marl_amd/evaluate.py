@@ -104,3 +104,25 @@ def eval_model_co(env, policy, itr, **kwargs):
     if out[0] is None:
         return out
     return out[0], out[1], out[2], [out[3]] * len(out[0])
+
+
+def eval_simple(args, env, algo, _eval=eval_model):
+    """exp_runners/predatorprey/eval_pp.py:107-157 (`--mode eval`): ``args.n_eval_episodes`` episodes of at most
+    ``args.max_env_steps`` steps with the algo's policy, printing the average length of the episodes that ended
+    before the step limit.  The reference's loop exists to drive ``env.my_render`` (UI, out of scope): with
+    ``args.render`` set this raises, otherwise the episodes are played as one batched device rollout (eval_model)."""
+    import time
+    start = time.time()
+    data, _succ, _rew, _bound = _eval(env, algo.policy, 0, n_eval_episodes=args.n_eval_episodes,
+                                      max_env_steps=args.max_env_steps, eval_greedy=bool(args.eval_greedy),
+                                      render=bool(getattr(args, "render", False)),
+                                      inspect_steps=bool(getattr(args, "inspect_steps", False)))
+    traj_len = [len(step_success) for step_success, _ in data if len(step_success) < args.max_env_steps]
+    print('Average trajectory length = {}'.format(np.mean(traj_len) if traj_len else float('nan')))
+    print(f'test_time: {time.time() - start}')
+    return traj_len
+
+
+def eval_simple_co(args, env, algo):
+    """exp_runners/coverage/eval_co.py:104-150: the same loop on the coverage env."""
+    return eval_simple(args, env, algo, _eval=eval_model_co)

@@ -163,13 +163,14 @@ class RolloutEngine:
             if st is not None:
                 cur.wait_stream(st)
 
-    def _wrap(self):
-        """Carry the last slot of the previous chunk into slot 0 (what `obses = next_obses` does)."""
-        self.obs[0].copy_(self.obs[self.H])
+    def _wrap(self, n=None):
+        """Carry the last slot written by an n-step chunk into slot 0 (what `obses = next_obses` does)."""
+        n = self.H if n is None else n
+        self.obs[0].copy_(self.obs[n])
         if self.dist_adj is not None:
-            self.dist_adj[0].copy_(self.dist_adj[self.H])
+            self.dist_adj[0].copy_(self.dist_adj[n])
         if self.channels is not None:
-            self.channels[0].copy_(self.channels[self.H])
+            self.channels[0].copy_(self.channels[n])
 
     def _strides(self):
         e = self.env
@@ -206,41 +207,67 @@ class RolloutEngine:
         self._fused = True
         return True
 
-    def run_chunk(self, use_graph=True):
-        """H steps filling every slot: one persistent launch per shard where the library has a fused kernel for the
-        shape; otherwise H x (policy, env) launches - replayed from one hipGraph with use_graph."""
-        if self._persistent and self.steps_fused(0, self.H):
-            self.step_base.add_(self.H)
-            self._wrap()
+    def prepare_graph(self, n=None):
+        """Capture + instantiate the hipGraph of an n-step chunk (n <= H, default H) WITHOUT advancing the rollout:
+        returns the graph, ready to replay.  One-time host-side setup that must not happen inside a capture (the weight
+        pack, the kernels' hipFuncSetAttribute calls) is triggered by one scratch step whose effects are undone: the
+        env state is snapshotted before and restored after it, and every trajectory slot it wrote is rewritten by the
+        chunk itself.  Call it before a timed region; run_chunk() calls it on first use otherwise."""
+        n = self.H if n is None else int(n)
+        assert 1 <= n <= self.H
+        g = self._graphs.get(n)
+        if g is not None:
+            return g
+        self.policy.sync_weights()
+        if not self._graphs:                                # first capture of this engine: the scratch step
+            saved = [part.get_state() for part in self.parts]
+            self._capturing = True                          # the two-launch form, exactly what the capture will issue
+            try:
+                self.fork()
+                self.step(0)
+                self.join()
+            finally:
+                self._capturing = False
+            torch.cuda.synchronize(self.env.device)
+            for part, st in zip(self.parts, saved):
+                part.set_state(**st)
+        torch.cuda.synchronize(self.env.device)
+        g = torch.cuda.CUDAGraph()
+        self._capturing = True
+        try:
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):   # NCCL's watchdog thread may touch HIP during capture
+                self.fork()
+                for t in range(n):
+                    self.step(t)
+                self.join()
+                self.step_base.add_(n)
+                self._wrap(n)
+        finally:
+            self._capturing = False
+        self._graphs[n] = g
+        return g
+
+    def run_chunk(self, use_graph=True, n=None):
+        """n steps (default: the whole horizon H) from slot 0, filling slots 0..n-1 (+ slot n of obs / masks), then
+        carrying slot n into slot 0 and advancing the sampler's Philox base by n: one persistent launch per shard
+        where the library has a fused kernel for the shape and the engine was built with persistent=True; otherwise
+        n x (policy, env) launches - replayed from one hipGraph per chunk length with use_graph.  The graph path and
+        the eager path produce the same trajectory slot by slot (tests/test_hip_ppo_parity.py)."""
+        n = self.H if n is None else int(n)
+        assert 1 <= n <= self.H
+        if self._persistent and self.steps_fused(0, n):
+            self.step_base.add_(n)
+            self._wrap(n)
             return
         if not use_graph:
             self.fork()
-            for t in range(self.H):
+            for t in range(n):
                 self.step(t)
             self.join()
-            self.step_base.add_(self.H)
-            self._wrap()
+            self.step_base.add_(n)
+            self._wrap(n)
             return
-        g = self._graphs.get("chunk")
-        if g is None:
-            # warm-up outside capture: first-call attribute setup + weight pack must not be captured
-            self.fork()
-            self.step(0)
-            self.join()
-            torch.cuda.synchronize(self.env.device)
-            g = torch.cuda.CUDAGraph()
-            self._capturing = True
-            try:
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):   # NCCL's watchdog thread may touch HIP during capture
-                    self.fork()
-                    for t in range(self.H):
-                        self.step(t)
-                    self.join()
-                    self.step_base.add_(self.H)
-                    self._wrap()
-            finally:
-                self._capturing = False
-            self._graphs["chunk"] = g
+        g = self._graphs.get(n) or self.prepare_graph(n)
         self.policy.sync_weights()          # in-place refresh of the weight pack the graph points at
         g.replay()
 

@@ -17,29 +17,104 @@ from .rollout import RolloutEngine
 
 
 class _Tabular:
-    """dowel.tabular stand-in: the reference records timers into a global table (sampler.py:236-239)."""
+    """The reference records its timers and progress columns into the global ``dowel.tabular``
+    (sampler.py:236-239, centralized_ma_ppo.py:345-385), which the runner dumps to progress.csv.  ``record`` keeps the
+    row here (``rows``: what tests and bench.py read) AND forwards it to ``dowel.tabular`` when dowel is importable,
+    so the reference's logger sees every column this package produces."""
 
     def __init__(self):
         self.rows = {}
+        self._dowel = None                     # None = not looked up yet, False = not importable
+
+    def _sink(self):
+        if self._dowel is None:
+            try:
+                import dowel
+                self._dowel = dowel.tabular
+            except Exception:
+                self._dowel = False
+        return self._dowel
 
     def record(self, k, v):
         self.rows[k] = v
+        sink = self._sink()
+        if sink:
+            sink.record(k, v)
 
 
 tabular = _Tabular()
+
+# which engine buffers a path key is built from (host copies are made per buffer, on first use)
+_PATH_KEYS = ("observations", "actions", "avail_actions", "rewards", "rewards_details", "dones", "dist_adjs", "channels",
+              "attentions", "ave_degs", "diameters", "ave_trputs", "success", "agent_infos", "env_infos")
+
+
+class _LazyPath(dict):
+    """One path dict of the reference's format whose values are built on first access: the runner's
+    ``sum(len(p['rewards']) for p in paths)`` (local_runner_wrapper.py:50-52) then costs one host copy of the reward
+    buffer instead of the whole trajectory.  It IS a dict (isinstance, ==, pickling after ``materialize()``)."""
+
+    def __init__(self, batch, i):
+        super().__init__()
+        self._batch, self._i = batch, i
+
+    def __missing__(self, k):
+        if k not in _PATH_KEYS:
+            raise KeyError(k)
+        v = self._batch._build(self._i, k)
+        dict.__setitem__(self, k, v)
+        return v
+
+    def materialize(self):
+        for k in _PATH_KEYS:
+            self[k]
+        return self
+
+    def __contains__(self, k):
+        return k in _PATH_KEYS
+
+    def __iter__(self):
+        return iter(_PATH_KEYS)
+
+    def __len__(self):
+        return len(_PATH_KEYS)
+
+    def keys(self):
+        return list(_PATH_KEYS)
+
+    def values(self):
+        return [self[k] for k in _PATH_KEYS]
+
+    def items(self):
+        return [(k, self[k]) for k in _PATH_KEYS]
+
+    def get(self, k, default=None):
+        return self[k] if k in _PATH_KEYS else default
+
+    def __eq__(self, other):
+        return dict(self.items()) == (dict(other.items()) if isinstance(other, _LazyPath) else other)
+
+    def __reduce__(self):
+        return (dict, (dict(self.items()),))
+
+    def __repr__(self):
+        return f"<path {self._i}: {len(self['rewards'])} steps>"
 
 
 class PathBatch(Sequence):
     """Completed paths of one obtain_samples call.
 
     Device side: time-major trajectory tensors of the engine (valid until the next call) plus
-    ``env_idx`` / ``start`` / ``length`` [P] (int64, device).  ``batch[i]`` builds the i-th
-    reference path dict (keys and shapes of SURVEY.md §3.2)."""
+    ``env_idx`` / ``start`` / ``length`` [P] (int64, device).  ``batch[i]`` and iteration give the i-th
+    reference path dict (keys and shapes of SURVEY.md §3.2) as a lazily filled dict: each value comes to the
+    host the first time it is read, one engine buffer at a time."""
 
     def __init__(self, engine, env_idx, start, length, n_agents):
         self.engine, self.env_idx, self.start, self.length = engine, env_idx, start, length
         self.n_agents = n_agents
-        self._host = None
+        self._bufs = {}                       # engine buffer name -> numpy (host copies made so far)
+        self._idx = None
+        self._T = None
 
     def __len__(self):
         return int(self.length.numel())
@@ -48,65 +123,97 @@ class PathBatch(Sequence):
     def n_samples(self):
         return int(self.length.sum().item()) * self.n_agents
 
-    def _to_host(self):
-        if self._host is None:
-            e = self.engine
-            T = int((self.start + self.length).max().item()) if len(self) else 0
-            h = dict(env_idx=self.env_idx.cpu().numpy(), start=self.start.cpu().numpy(), length=self.length.cpu().numpy())
-            for k in ("obs", "actions", "probs", "attn", "reward64", "done", "details", "prey_alive", "success",
-                      "dist_adj", "channels"):
-                t = getattr(e, k)
-                h[k] = None if t is None else t[:T + (1 if k in ("obs", "dist_adj", "channels") else 0)].cpu().numpy()
-            self._host = h
-        return self._host
+    @property
+    def host_buffers(self):
+        """Names of the engine buffers copied to the host so far (tests pin the cheap paths with this)."""
+        return sorted(self._bufs)
+
+    def _index(self):
+        if self._idx is None:
+            self._idx = (self.env_idx.cpu().numpy(), self.start.cpu().numpy(), self.length.cpu().numpy())
+            self._T = int((self._idx[1] + self._idx[2]).max()) if len(self._idx[0]) else 0
+        return self._idx
+
+    def _buf(self, name):
+        if name not in self._bufs:
+            self._index()
+            t = getattr(self.engine, name)
+            extra = 1 if name in ("obs", "dist_adj", "channels") else 0
+            self._bufs[name] = None if t is None else t[:self._T + extra].cpu().numpy()
+        return self._bufs[name]
 
     def __getitem__(self, i):
         if isinstance(i, slice):
             return [self[j] for j in range(*i.indices(len(self)))]
         if i < 0:
             i += len(self)
-        h = self._to_host()
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        return _LazyPath(self, i)
+
+    def __iter__(self):
+        return (_LazyPath(self, i) for i in range(len(self)))
+
+    def _build(self, i, key):
+        env_idx, start, length = self._index()
         e = self.engine
-        b, s, n = int(h["env_idx"][i]), int(h["start"][i]), int(h["length"][i])
-        N, Lh = e.env.N, e.env.Lh
-        sl = slice(s, s + n)
         env = e.env
-        obs = h["obs"][sl, b].reshape(n, -1).astype(np.float64)
-        if h["dist_adj"] is not None:
-            adj = h["dist_adj"][sl, b].reshape(n, N * N)
-        else:
-            adj = np.ones((n, N * N), np.float64)                          # get_graph Rcom == 0 (:219-223)
-        if h["channels"] is not None:
-            ch = h["channels"][sl, b].reshape(n, Lh * N, N)
-        else:
-            c1 = env.channels[0].cpu().numpy().reshape(Lh * N, N)
-            ch = np.broadcast_to(c1, (n, Lh * N, N)).copy()
-        det = h["details"][sl, b]
+        b, s, n = int(env_idx[i]), int(start[i]), int(length[i])
+        N, Lh = env.N, env.Lh
+        sl = slice(s, s + n)
         pp = env.scenario == "pp"
-        nA = float(N)
-        details = []
-        for k in range(n):
-            dd = det[k]
-            if pp:
-                details.append(dict(reward=float(h["reward64"][s + k, b]), capture_cnt=int(dd[0]), step_cnt=1,
-                                    move_cnt=dd[1] / nA, penalty_cnt=int(dd[2]), variable=dd[4] / nA, vars2=0))
-            else:
-                details.append(dict(reward=float(h["reward64"][s + k, b]), capture_cnt=dd[0] / nA, step_cnt=1,
-                                    move_cnt=dd[1] / nA, penalty_cnt=dd[2] / nA, variable=dd[4] / nA, vars2=dd[3] / nA))
-        attn = h["attn"][sl, b] if h["attn"] is not None else None
-        probs = h["probs"][sl, b] if h["probs"] is not None else None
-        ave_deg = adj.reshape(n, N, N).sum(-1).mean(-1) if h["dist_adj"] is not None else np.full(n, N)
-        path = dict(
-            observations=obs, actions=h["actions"][sl, b].astype(np.int64),
-            avail_actions=np.ones((n, N * 5), dtype=np.int64), rewards=h["reward64"][sl, b].copy(),
-            rewards_details=np.asarray(details), dones=h["done"][sl, b].astype(bool),
-            dist_adjs=adj, channels=ch, attentions=attn,
-            ave_degs=ave_deg, diameters=np.full(n, N if h["dist_adj"] is None else 0),
-            ave_trputs=np.full(n, env.n_empty_cells if not pp else 0),
-            success=h["success"][s + n - 1].astype(np.int64),             # [n_envs], read when the path ended (:194)
-            agent_infos=dict(action_probs=probs, attention_weights=attn),
-            env_infos=dict(prey_alive=h["prey_alive"][sl, b].astype(bool)) if h["prey_alive"] is not None else {})
-        return path
+        if key == "observations":
+            return self._buf("obs")[sl, b].reshape(n, -1).astype(np.float64)
+        if key == "actions":
+            return self._buf("actions")[sl, b].astype(np.int64)
+        if key == "avail_actions":
+            return np.ones((n, N * 5), dtype=np.int64)
+        if key == "rewards":
+            return self._buf("reward64")[sl, b].copy()
+        if key == "dones":
+            return self._buf("done")[sl, b].astype(bool)
+        if key == "dist_adjs":
+            h = self._buf("dist_adj")
+            return h[sl, b].reshape(n, N * N) if h is not None else np.ones((n, N * N), np.float64)   # get_graph Rcom == 0 (:219-223)
+        if key == "channels":
+            h = self._buf("channels")
+            if h is not None:
+                return h[sl, b].reshape(n, Lh * N, N)
+            if "_const_ch" not in self._bufs:
+                self._bufs["_const_ch"] = env.channels[0].cpu().numpy().reshape(Lh * N, N)
+            return np.broadcast_to(self._bufs["_const_ch"], (n, Lh * N, N)).copy()
+        if key == "attentions":
+            h = self._buf("attn")
+            return None if h is None else h[sl, b]
+        if key == "ave_degs":
+            h = self._buf("dist_adj")
+            return h[sl, b].reshape(n, N, N).sum(-1).mean(-1) if h is not None else np.full(n, N)
+        if key == "diameters":
+            return np.full(n, N if e.dist_adj is None else 0)
+        if key == "ave_trputs":
+            return np.full(n, env.n_empty_cells if not pp else 0)
+        if key == "success":
+            return self._buf("success")[s + n - 1].astype(np.int64)       # [n_envs], read when the path ended (:194)
+        if key == "agent_infos":
+            pr, at = self._buf("probs"), self._buf("attn")
+            return dict(action_probs=None if pr is None else pr[sl, b], attention_weights=None if at is None else at[sl, b])
+        if key == "env_infos":
+            h = self._buf("prey_alive")
+            return dict(prey_alive=h[sl, b].astype(bool)) if h is not None else {}
+        if key == "rewards_details":
+            det, rew = self._buf("details")[sl, b], self._buf("reward64")
+            nA = float(N)
+            details = []
+            for k in range(n):
+                dd = det[k]
+                if pp:
+                    details.append(dict(reward=float(rew[s + k, b]), capture_cnt=int(dd[0]), step_cnt=1,
+                                        move_cnt=dd[1] / nA, penalty_cnt=int(dd[2]), variable=dd[4] / nA, vars2=0))
+                else:
+                    details.append(dict(reward=float(rew[s + k, b]), capture_cnt=dd[0] / nA, step_cnt=1,
+                                        move_cnt=dd[1] / nA, penalty_cnt=dd[2] / nA, variable=dd[4] / nA, vars2=dd[3] / nA))
+            return np.asarray(details)
+        raise KeyError(key)
 
 
 class CentralizedMAOnPolicyVectorizedSampler:
@@ -149,6 +256,36 @@ class CentralizedMAOnPolicyVectorizedSampler:
             self._capacity = horizon
         return self.engine
 
+    def _kernel_split(self, eng):
+        """Share of a step's GPU time spent in the policy kernel, measured once per engine with HIP events on a
+        scratch step (policy forward x3, env step x1; the env state is snapshotted and restored, and the slots the
+        scratch step writes are rewritten by the rollout).  The stepping loop runs policy + env as ONE fused launch
+        per step, so the two timers the reference reports separately (sampler.py:236-237) are the loop's measured
+        GPU time split by this ratio."""
+        if getattr(eng, "_pol_share", None) is not None:
+            return eng._pol_share
+        part, (lo, hi) = eng.parts[0], eng.bounds[0]
+        nb = hi - lo
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        saved = part.get_state()
+        kw = dict(out_actions=eng.actions[0][lo:hi], out_probs=None if eng.probs is None else eng.probs[0][lo:hi],
+                  out_attn=None if eng.attn is None else eng.attn[0][lo:hi], policy_step=0, step_base=eng.step_base,
+                  env_id_offset=eng.id0 + lo)
+        args = (eng.obs[0][lo:hi].view(nb, -1), None, None if eng.dist_adj is None else eng.dist_adj[0][lo:hi],
+                None if eng.channels is None else eng.channels[0][lo:hi])
+        self.algo.policy.act_device(*args, **kw)                       # untimed first call
+        ev[0].record()
+        for _ in range(3):
+            self.algo.policy.act_device(*args, **kw)
+        ev[1].record()
+        part.step_device(eng.actions[0][lo:hi], out=eng._out(0, lo, hi))
+        ev[2].record()
+        ev[2].synchronize()
+        t_pol, t_env = ev[0].elapsed_time(ev[1]) / 3.0, ev[1].elapsed_time(ev[2])
+        part.set_state(**saved)
+        eng._pol_share = t_pol / max(t_pol + t_env, 1e-9)
+        return eng._pol_share
+
     def obtain_samples(self, itr, batch_size=None, whole_paths=True, chunk=32):
         """Roll until the completed paths hold >= batch_size agent-steps (:119), checking the stop
         rule once per `chunk` steps on the device; returns the completed paths up to the exact step
@@ -162,10 +299,12 @@ class CentralizedMAOnPolicyVectorizedSampler:
         eng = self._ensure_engine(horizon)
         policy = self.algo.policy
         policy.sync_weights()
-        t_pol = t_env = 0.0
         t_all = time.time()
         eng.reset()
         policy.reset([True] * B)
+        pol_share = self._kernel_split(eng)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
         t, stop_t = 0, None
         while stop_t is None:
             t1 = min(t + chunk, horizon)
@@ -180,6 +319,7 @@ class CentralizedMAOnPolicyVectorizedSampler:
             elif t1 >= horizon:
                 raise RuntimeError("sampler horizon exhausted before batch_size was reached (bug in the bound)")
             t = t1
+        ev1.record()
         self.batch.check_status()
         T = stop_t
         # completed paths within [0, T): every (t, b) with path_len > 0
@@ -190,9 +330,10 @@ class CentralizedMAOnPolicyVectorizedSampler:
         paths = PathBatch(eng, idx[:, 1], start, length, N)
         torch.cuda.synchronize(self.batch.device)
         total = time.time() - t_all
-        tabular.record('PolicyExecTime', t_pol)                   # not separable without per-step syncs
-        tabular.record('EnvExecTime', t_env)
-        tabular.record('ProcessExecTime', total)
+        gpu = ev0.elapsed_time(ev1) * 1e-3                         # seconds of the stepping loop on the device
+        tabular.record('PolicyExecTime', gpu * pol_share)          # sampler.py:236-239
+        tabular.record('EnvExecTime', gpu * (1.0 - pol_share))
+        tabular.record('ProcessExecTime', max(total - gpu, 0.0))   # host-side bookkeeping around the device loop
         tabular.record('BoundReturn', float(getattr(self._base, "bound_return", 0.0)))
         self.last_steps = T
         if not whole_paths:

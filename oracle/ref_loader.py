@@ -110,6 +110,10 @@ def _install_third_party_stubs():
         def dump_all(self, *a, **k):
             pass
 
+        def prefix(self, *_a):
+            import contextlib
+            return contextlib.nullcontext()
+
     class _Tabular:
         def __init__(self):
             self.rows = {}
@@ -120,6 +124,9 @@ def _install_third_party_stubs():
         def prefix(self, *_a):
             import contextlib
             return contextlib.nullcontext()
+
+        def clear(self):
+            self.rows = {}
 
     _mod("dowel", logger=_Logger(), tabular=_Tabular(), StdOutput=object)
 

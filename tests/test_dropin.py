@@ -22,14 +22,190 @@ def test_install_registers_reference_import_names():
         from com_marl.torch.baselines import GaussianMLPBaseline                  # noqa: F401
         from com_marl.torch.algos import CentralizedMAPPO                         # noqa: F401
         from com_marl.sampler import CentralizedMAOnPolicyVectorizedSampler       # noqa: F401
-        from eval_pp import eval_model                                            # noqa: F401
-        from eval_co import eval_model as eval_model_co                           # noqa: F401
+        from eval_pp import eval_simple, eval_model                               # noqa: F401  (runner_pp_commDP.py:35)
+        from eval_co import eval_simple as es_co, eval_model as eval_model_co     # noqa: F401
         assert "com_marl.torch.policies" in names and "eval_co" in names
         assert CommBaseCritic.__module__.startswith("com_marl_amd")
     finally:
         for k in [k for k, v in sys.modules.items() if getattr(v, "_commarl_amd", False)]:
             del sys.modules[k]
         sys.modules.update(saved)
+
+
+def _purge_aliases():
+    saved = {k: v for k, v in sys.modules.items()
+             if (k in ("envs", "garage", "dowel", "eval_pp", "eval_co") or k.startswith(("envs.", "com_marl", "garage.")))
+             and not k.startswith("com_marl_amd")}
+    for k in saved:
+        del sys.modules[k]
+    return saved
+
+
+def _restore_aliases(saved):
+    for k in [k for k, v in sys.modules.items() if getattr(v, "_commarl_amd", False) or k in ("garage", "dowel")
+              or k.startswith("garage.")]:
+        del sys.modules[k]
+    sys.modules.update(saved)
+    import com_marl_amd.dropin as dropin
+    sys.meta_path[:] = [f for f in sys.meta_path if not isinstance(f, dropin._BaseSamplerHook)]
+
+
+def _stub_garage_base():
+    """garage.sampler.base as the reference ships it (garage/sampler/base.py:4-49): Sampler(abc.ABC) with three
+    abstract methods, BaseSampler(Sampler) storing algo / env."""
+    import abc
+    import types
+
+    class Sampler(abc.ABC):
+        @abc.abstractmethod
+        def start_worker(self):
+            pass
+
+        @abc.abstractmethod
+        def obtain_samples(self, itr, batch_size, whole_paths):
+            pass
+
+        @abc.abstractmethod
+        def shutdown_worker(self):
+            pass
+
+    class BaseSampler(Sampler):
+        def __init__(self, algo, env):
+            self.algo, self.env = algo, env
+    m = types.ModuleType("garage.sampler.base")
+    m.Sampler, m.BaseSampler = Sampler, BaseSampler
+    return m
+
+
+def _runner_gates(sampler_cls, sampler, BaseSampler):
+    """The two gates of the reference runner, restated: LocalRunner.make_sampler (garage/experiment/
+    local_runner.py:181-189) and LocalRunnerWrapper.obtain_samples (com_marl/experiment/local_runner_wrapper.py:41-47)."""
+    return issubclass(sampler_cls, BaseSampler), isinstance(sampler, BaseSampler)
+
+
+@pytest.mark.parametrize("order", ["garage_first", "install_first"])
+def test_sampler_is_a_base_sampler_for_the_reference_runner(order, tmp_path):
+    """The runner takes its BaseSampler branch for our sampler whichever of `import garage...` / `dropin.install()`
+    comes first: registration happens at install() when garage.sampler.base is loaded already, else by an import
+    hook the moment it is."""
+    import types
+    saved = _purge_aliases()
+    try:
+        import com_marl_amd.dropin as dropin
+        from com_marl_amd.sampler import CentralizedMAOnPolicyVectorizedSampler as S
+        if order == "garage_first":
+            sys.modules["garage.sampler.base"] = _stub_garage_base()
+            dropin.install()
+            base = sys.modules["garage.sampler.base"]
+        else:
+            # a real importable garage/sampler/base.py on sys.path, imported AFTER install()
+            pkg = tmp_path / "garage" / "sampler"
+            pkg.mkdir(parents=True)
+            (tmp_path / "garage" / "__init__.py").write_text("")
+            (pkg / "__init__.py").write_text("")
+            (pkg / "base.py").write_text(
+                "import abc\n"
+                "class Sampler(abc.ABC):\n"
+                "    @abc.abstractmethod\n"
+                "    def start_worker(self): pass\n"
+                "    @abc.abstractmethod\n"
+                "    def obtain_samples(self, itr, batch_size, whole_paths): pass\n"
+                "    @abc.abstractmethod\n"
+                "    def shutdown_worker(self): pass\n"
+                "class BaseSampler(Sampler):\n"
+                "    def __init__(self, algo, env):\n"
+                "        self.algo, self.env = algo, env\n")
+            dropin.install()
+            sys.path.insert(0, str(tmp_path))
+            try:
+                import importlib
+                base = importlib.import_module("garage.sampler.base")
+            finally:
+                sys.path.remove(str(tmp_path))
+        from com_marl.sampler import CentralizedMAOnPolicyVectorizedSampler as S2
+        assert S2 is S
+        shell = types.SimpleNamespace(batch=types.SimpleNamespace(B=3, N=4), spec=None)
+        smp = S(algo=types.SimpleNamespace(policy=None, max_path_length=9), env=shell, n_envs=3)   # the runner's ctor call
+        assert _runner_gates(S, smp, base.BaseSampler) == (True, True)
+        assert not issubclass(dict, base.BaseSampler)
+    finally:
+        _restore_aliases(saved)
+
+
+def test_reference_runner_accepts_the_sampler_class():
+    """With the reference tree present (build container only): the reference's own LocalRunnerWrapper.setup() builds
+    our sampler through the BaseSampler branch of make_sampler, and its obtain_samples() gate holds."""
+    import os
+    import types
+    if not os.path.isdir(os.environ.get("COMMARL_REFERENCE", "/root/reference")):
+        pytest.skip("reference tree not present (GPU box)")
+    saved = _purge_aliases()
+    try:
+        import importlib
+        import tempfile
+        from oracle import ref_loader as R
+        R.load_reference_ppo()
+        lr = importlib.import_module("garage.experiment.local_runner")
+        sys.modules["garage.experiment"].LocalRunner = lr.LocalRunner
+        import com_marl_amd.dropin as dropin
+        dropin.install(force=True)
+        wrap = importlib.import_module("com_marl.experiment.local_runner_wrapper")     # the reference's, via __path__
+        assert wrap.__file__.startswith(os.environ.get("COMMARL_REFERENCE", "/root/reference"))
+        from com_marl.sampler import CentralizedMAOnPolicyVectorizedSampler as S
+        assert S.__module__.startswith("com_marl_amd")
+        cfg = types.SimpleNamespace(snapshot_dir=tempfile.mkdtemp(), snapshot_mode="none", snapshot_gap=1)
+        runner = wrap.LocalRunnerWrapper(cfg, eval=False, save_env=False)
+        algo = types.SimpleNamespace(policy=types.SimpleNamespace(centralized=True), max_path_length=9, sampler_cls=S)
+        env = types.SimpleNamespace(batch=types.SimpleNamespace(B=3, N=4), spec=None, n_agents=4)
+        runner.setup(algo, env, sampler_cls=S, sampler_args={"n_envs": 3})            # runner_pp_commDP.py:145-151
+        assert type(runner._sampler) is S and runner._sampler._n_envs == 3
+        assert isinstance(runner._sampler, sys.modules["garage.sampler.base"].BaseSampler)
+    finally:
+        _restore_aliases(saved)
+        for k in [k for k in sys.modules if k in ("gym", "akro", "pyprind", "send2trash", "pynvml", "custom_implement")
+                  or k.startswith(("gym.", "custom_implement."))]:
+            del sys.modules[k]
+
+
+def test_runner_contract_recording():
+    """What the reference's LocalRunnerWrapper.train() does to a sampler and to `paths` (recorded from the reference
+    itself by oracle/gen_runner_contract.py): a class that is only BaseSampler.register()-ed takes the BaseSampler
+    branches, and `paths` is only iterated with p['rewards'] read per path."""
+    import json
+    import os
+    z = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "runner_contract.json")))
+    evs = z["events"]
+    names = [e[0] for e in evs]
+    assert "sampler.from_worker_factory" not in names
+    assert evs[0] == ["sampler.__init__", [["n_envs", 3]], "Algo", "Env"]
+    assert ["runner.setup done", "RecSampler", True] in evs
+    calls = [e for e in evs if e[0] == "sampler.obtain_samples"]
+    assert [c[2:] for c in calls] == [[48, True, []], [48, True, []]]               # (itr, batch_size), no agent_update
+    assert {tuple(e) for e in evs if e[0].startswith("path")} == {("paths.__iter__",), ("path.__getitem__", "rewards")}
+    assert z["total_env_steps_increments"] == [sum(x) for x in reversed(z["path_lengths"])]   # itr 1, then itr 2
+
+
+def test_tabular_forwards_to_dowel():
+    """Timers and progress columns reach dowel.tabular when dowel is importable (sampler.py:236-239 /
+    centralized_ma_ppo.py:345-385 record into it)."""
+    import types
+    from com_marl_amd.sampler import _Tabular
+    had = sys.modules.get("dowel")
+    rows = {}
+    sys.modules["dowel"] = types.SimpleNamespace(tabular=types.SimpleNamespace(record=rows.__setitem__))
+    try:
+        t = _Tabular()
+        t.record("PolicyExecTime", 0.25)
+        assert rows == {"PolicyExecTime": 0.25} and t.rows == rows
+    finally:
+        if had is None:
+            del sys.modules["dowel"]
+        else:
+            sys.modules["dowel"] = had
+    t = _Tabular()
+    t._dowel = False                        # dowel absent: rows are still kept
+    t.record("EnvExecTime", 1.0)
+    assert t.rows == {"EnvExecTime": 1.0}
 
 
 def test_state_dict_names_match_reference():
@@ -152,3 +328,37 @@ def test_single_env_wrapper_keeps_reference_shapes():
     assert r.shape == (3,) and done.shape == (3,) and len(det) == 3 and info == {}
     with pytest.raises(Exception):
         env.step(np.array([0, 1, 2, 9]))                                   # 'Action Not found!' (:255)
+
+
+@pytest.mark.gpu
+def test_paths_replay_of_the_reference_runner_contract():
+    """The operations the reference runner applies to `paths` (tests/golden/runner_contract.json, recorded from
+    LocalRunnerWrapper.train): iterate, p['rewards'], len - on a PathBatch they give the same total as the device-side
+    index and copy ONE buffer (the f64 rewards) to the host, not the trajectory; the three timers are real."""
+    import json
+    import os
+    import torch
+    from com_marl_amd import sampler as S
+    from tests.test_hip_ppo_parity import _small_setup
+    z = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "runner_contract.json")))
+    ops = {tuple(e) for e in z["events"] if e[0].startswith("path")}
+    assert ops == {("paths.__iter__",), ("path.__getitem__", "rewards")}
+    env, pol, crit, algo, smp = _small_setup(torch, B=64, mpl=12, scenario="pp")
+    smp.start_worker()
+    paths = smp.obtain_samples(1, 64 * 4 * 12)                          # (itr, batch_size) as recorded
+    total = sum([len(p['rewards']) for p in paths])                      # local_runner_wrapper.py:50-52
+    assert total == int(paths.length.sum().item()) and total >= 64 * 12
+    assert paths.host_buffers == ["reward64"]
+    rows = S.tabular.rows
+    assert rows["PolicyExecTime"] > 0 and rows["EnvExecTime"] > 0 and rows["ProcessExecTime"] >= 0
+    gpu = rows["PolicyExecTime"] + rows["EnvExecTime"]
+    assert 1e-5 < gpu < 5.0
+    # a path is a real dict with the reference's keys; values appear on first access
+    p0 = paths[0]
+    assert isinstance(p0, dict) and "observations" in p0 and len(p0) == 15
+    assert p0["observations"].shape == (len(p0["rewards"]), 4 * 21)
+    assert "obs" in paths.host_buffers and "attn" not in paths.host_buffers
+    import pickle
+    q = pickle.loads(pickle.dumps(p0))
+    assert type(q) is dict and set(q) == set(p0.keys())
+    np.testing.assert_array_equal(q["actions"], p0["actions"])

@@ -89,7 +89,7 @@ def test_run_chunk_uses_the_persistent_kernel_and_matches_stepwise_launches():
     from com_marl_amd.rollout import RolloutEngine
     scen, map_, sen, N, M, load, loss, B, steps, mpl = SHAPES["pp_map10"]
     outs = []
-    for persistent in (True, False):
+    for persistent, use_graph in ((True, False), (False, False), (False, True)):
         shards = [E.GridEnvBatch(scen, _params(scen, map_, sen, N, M, load, loss, mpl), 64, device="cuda:0", seed=3,
                                  max_steps=mpl, max_path_length=mpl, env_id_offset=64 * k) for k in range(2)]
         spec = E.EnvSpec(E._Box(np.zeros(shards[0].d * N), np.ones(shards[0].d * N)), E._Discrete(5))
@@ -99,13 +99,14 @@ def test_run_chunk_uses_the_persistent_kernel_and_matches_stepwise_launches():
         eng = RolloutEngine(shards, pol, 12, persistent=persistent)   # persistent is opt-in
         eng.reset()
         for _ in range(3):
-            eng.run_chunk(use_graph=False)      # (graph capture spends one extra warm-up step: not comparable slot by slot)
+            eng.run_chunk(use_graph=use_graph)  # graph capture does not advance the rollout: comparable slot by slot
         torch.cuda.synchronize()
         eng.env.check_status()
-        assert eng._fused is True
+        assert use_graph or eng._fused is True
         outs.append([getattr(eng, k).cpu().numpy() for k in ("obs", "actions", "probs", "reward64", "done", "path_len")])
-    for x, y in zip(*outs):
-        np.testing.assert_array_equal(x, y)
+    for other in outs[1:]:
+        for x, y in zip(outs[0], other):
+            np.testing.assert_array_equal(x, y)
 
 
 def test_fused_entry_point_reports_unavailable_and_errors():
