@@ -402,6 +402,32 @@ def record_adj_ties(ns, seed=3):
     return out
 
 
+def record_adj_ties_grid32(ns, seed=17):
+    """As record_adj_ties, with every position inside a 32 x 32 grid (the device env's largest side) so that the
+    recorded adjacency can be driven through the oracle AND the HIP env step: distinct cells, a diamond of exact ties
+    (p, p+(9,9), p+(9,-9), p+(18,0): four pairs at dx^2+dy^2 == 162) plus near-ties on both sides (161, 164)."""
+    rng = np.random.RandomState(seed)
+    out = {}
+    x = torch.FloatTensor([[0, 0], [9, 9]])
+    th = torch.cdist(x, x)[0][-1]
+    for n in (4, 24, 26, 54, 72):
+        while True:
+            pos = rng.randint(0, 32, size=(n, 2))
+            p = np.array([rng.randint(0, 13), rng.randint(9, 22)])
+            pos[0], pos[1], pos[2], pos[3] = p, p + [9, 9], p + [9, -9], p + [18, 0]
+            if n > 6:
+                pos[4] = p + [10, 8]             # 164 > 162 from p: not adjacent
+                pos[5] = p + [12, 4] if n > 5 else pos[5]     # 160 <= 162: adjacent
+                pos[6] = p + [1, 0]              # from p+(9,9): 64+81 = 145; from p+(10,8): 81+64
+            if len({tuple(q) for q in pos}) == n and pos.min() >= 0 and pos.max() <= 31:
+                break
+        adj, deg, _ = ns.env_communication.get_graph(9, th, n, {i: list(map(int, pos[i])) for i in range(n)})
+        out[f'pos_{n}'] = pos.astype(np.int32)
+        out[f'adj_{n}'] = np.asarray(adj).astype(np.float32)
+        out[f'deg_{n}'] = np.float64(deg)
+    return out
+
+
 # --------------------------------------------------------------------------------------
 # policy / critic / PPO-math fixtures
 # --------------------------------------------------------------------------------------
@@ -709,7 +735,7 @@ def main():
         print(f'{name:28s} {os.path.getsize(path) / 1024:8.1f} KiB')
 
     fx = {}
-    if args.only and args.only.startswith(('ppo_step', 'variants_', 'ppo_math', 'adam')):
+    if args.only and args.only.startswith(('ppo_step', 'variants_', 'ppo_math', 'adam', 'adj_ties_grid32')):
         return late(save, args)
     # config 1/2: PP map10 sen1 den.04 cap2 (full 200-step horizon, chasing so captures happen)
     fx['pp_map10_cap2'] = record_env(ns, 'pp', pp_params(10, 1, 0.04, 2), B=3, T=230, seed=1, p_random=0.35)
@@ -771,6 +797,7 @@ def main():
 def late(save, args, ns=None):
     """Fixtures that do not need the env recordings of this run."""
     ns = ns or ref_loader.load_reference()
+    save('adj_ties_grid32', lambda: record_adj_ties_grid32(ns))
     save('ppo_math', lambda: record_ppo_math(ns))
     save('adam', lambda: record_adam(ns))
     save('ppo_step', lambda: record_ppo_step())

@@ -61,6 +61,9 @@ class HipEnv:
         self._refresh()
         return self.obs, self.reward, self.done
 
+    def load_state(self, **arrays):
+        self.batch.set_state(**arrays)
+
     def visited_dense(self):
         cols = np.arange(self.S, dtype=np.uint32)
         return ((self.visited[:, :, None] >> cols[None, None, :]) & 1).astype(np.uint8)

@@ -27,6 +27,13 @@ def test_env_hip_matches_reference_golden(path, hip):
     replay(path, hip.HipEnv)
 
 
+def test_adjacency_ties_through_the_hip_env_step(hip):
+    """The HIP env step emits the reference's adjacency on the tie-heavy recording (positions inside a 32 x 32 grid,
+    recorded from env_communication.get_graph): exact ties dx^2+dy^2 == 2*Rcom^2 are adjacent, 164 is not."""
+    from tests.test_oracle_golden import check_adjacency, drive_adjacency
+    check_adjacency(drive_adjacency(hip.HipEnv, "adj_ties_grid32.npz", 32))
+
+
 def _lockstep(cfg_kwargs, steps, hip, seed=1234, check_every=1):
     """Same Philox stream, same random actions through oracle and HIP; compare everything."""
     cfg_o = O.make_cfg(**cfg_kwargs, rng_mode=O.RNG_PHILOX, seed=seed)

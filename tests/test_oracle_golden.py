@@ -93,19 +93,50 @@ def test_ge_transition_direct():
     assert z["states"].min() == 0     # some links did go bad
 
 
-def test_adjacency_ties():
-    """Integer rule dx^2+dy^2 <= 2*Rcom^2 == f32 cdist <= Rcom_th incl. exact ties."""
-    z = np.load(os.path.join(GOLDEN, "adj_ties.npz"))
+def drive_adjacency(make_env, fixture, grid):
+    """Place the agents on the recorded tie-heavy positions, step once with every agent staying put, and return the
+    adjacency the ENV STEP emitted (update_communication_state -> get_graph, env_communication.py:218-243).  One far
+    prey keeps the PP episode alive (no prey -> done -> auto-reset would emit the reset's graph instead)."""
+    z = np.load(os.path.join(GOLDEN, fixture))
+    out = {}
     for n in (4, 24, 26, 54, 72):
-        cfg = O.make_cfg("pp", 1, n, 40, 1, n_preys=0, rcom=9, rng_mode=O.RNG_TAPE)
-        env = O.OracleEnv(cfg)
-        env.agent_pos[0] = z[f"pos_{n}"]
-        env.step_count[:] = 0
-        # a no-op step re-emits the adjacency (no preys -> done, so use max_steps large and M=0 => done)
-        pos = z[f"pos_{n}"].astype(np.int64)
-        d2 = ((pos[:, None, :] - pos[None, :, :]) ** 2).sum(-1)
-        np.testing.assert_array_equal((d2 <= 162).astype(np.float32), z[f"adj_{n}"])
-        assert ((d2 == 162).sum()) >= 2
+        pos = z[f"pos_{n}"]
+        cfg = O.make_cfg("pp", 1, n, grid, 1, n_preys=1, rcom=9, max_steps=50, rng_mode=O.RNG_PHILOX, seed=n)
+        env = make_env(cfg)
+        env.reset()
+        occupied = {tuple(q) for q in pos}
+        prey = next((r, c) for r in range(grid - 1, -1, -1) for c in range(grid - 1, -1, -1)
+                    if all((r + dr, c + dc) not in occupied for dr in (-1, 0, 1) for dc in (-1, 0, 1)))
+        yield_state = dict(agent_pos=pos[None].astype(np.int32), prey_pos=np.array([[prey]], np.int32),
+                           prey_alive=np.ones((1, 1), np.uint8), step_count=np.zeros(1, np.int32))
+        env.load_state(**yield_state)
+        env.step(np.full((1, n), 4, np.int32))
+        assert not env.done[0]
+        np.testing.assert_array_equal(env.agent_pos[0], pos)
+        out[n] = (env.dist_adj[0].copy(), z[f"adj_{n}"], float(z[f"deg_{n}"]), pos)
+    return out
+
+
+def check_adjacency(results):
+    for n, (got, want, deg, pos) in results.items():
+        np.testing.assert_array_equal(got, want, err_msg=f"N={n}")
+        assert abs(got.sum(1).mean() - deg) < 1e-5                       # ave_deg incl. self loops (:232)
+        d2 = ((pos[:, None, :].astype(np.int64) - pos[None, :, :]) ** 2).sum(-1)
+        assert (d2 == 162).sum() >= 2, "fixture should hold exact ties"
+        assert got[d2 == 162].all() and not got[d2 > 162].any()
+
+
+class _OracleWithLoad(O.OracleEnv):
+    def load_state(self, **arrays):
+        for k, v in arrays.items():
+            getattr(self, k)[...] = v
+
+
+@pytest.mark.parametrize("fixture,grid", [("adj_ties.npz", 40), ("adj_ties_grid32.npz", 32)])
+def test_adjacency_ties(fixture, grid):
+    """The oracle's env step emits exactly the reference's adjacency on the tie-heavy recordings: the integer rule
+    dx^2+dy^2 <= 2*Rcom^2 == f32 cdist <= Rcom_th incl. exact ties."""
+    check_adjacency(drive_adjacency(_OracleWithLoad, fixture, grid))
 
 
 def test_philox_known_answers():
