@@ -198,12 +198,20 @@ extern "C" int cm_env_create(const cm_env_cfg *cfg, cm_env_t *out) {
     d.base_grid = (const uint8_t *)(base + o_bg); d.lut_row = (const float *)(base + o_lr); d.lut_col = (const float *)(base + o_lc);
     d.lut_step = (const float *)(base + o_ls);
     d.rew_lut = (const double *)(base + o_rl);
-    hipMemcpy(base + o_rl, rew_lut.data(), rew_lut.size() * 8, hipMemcpyHostToDevice);
-    hipMemcpy(base + o_bg, walls.data(), walls.size(), hipMemcpyHostToDevice);
-    hipMemcpy(base + o_lr, lut_row.data(), S * 4, hipMemcpyHostToDevice);
-    hipMemcpy(base + o_lc, lut_col.data(), S * 4, hipMemcpyHostToDevice);
-    hipMemcpy(base + o_ls, lut_step.data(), (c.max_steps + 1) * 4, hipMemcpyHostToDevice);
-    if (c.channel == CM_CH_GE) hipMemset(base + o_ge, 1, B * N * N);
+    {   // constant tables and the initial GE state: a failed upload would leave silently wrong LUTs, so every copy is checked
+        struct Up { size_t off; const void *src; size_t bytes; const char *what; };
+        const Up ups[] = { { o_rl, rew_lut.data(), rew_lut.size() * 8, "reward LUT" }, { o_bg, walls.data(), walls.size(), "wall grid" },
+                           { o_lr, lut_row.data(), (size_t)S * 4, "row LUT" }, { o_lc, lut_col.data(), (size_t)S * 4, "column LUT" },
+                           { o_ls, lut_step.data(), (size_t)(c.max_steps + 1) * 4, "step LUT" } };
+        for (const Up &u : ups) {
+            e = hipMemcpy(base + u.off, u.src, u.bytes, hipMemcpyHostToDevice);
+            if (e != hipSuccess) { hipFree(h->arena); delete h; return hip_fail(e, u.what); }
+        }
+        if (c.channel == CM_CH_GE) {
+            e = hipMemset(base + o_ge, 1, B * N * N);
+            if (e != hipSuccess) { hipFree(h->arena); delete h; return hip_fail(e, "hipMemset(GE state)"); }
+        }
+    }
     d.lds_env = lds_env_bytes(S, c.n_agents, M ? M : 1);
     {   // lanes per env: the smallest sub-wave group that still gives every agent / prey its own lane
         // measured (tools/envscale.py): at N <= 8 the step is dominated by the group-uniform serial loops, so
@@ -275,8 +283,7 @@ static int launch(cm_env_t h, const int32_t *actions, const cm_rng_tape *tape, c
     if (wide_on && d.lpe == 64 && d.B <= 1536) {
         const dim3 wgrid((d.B + G_ - 1) / G_), wblock(256);
 #define CM_WIDE(SC, LP) hipLaunchKernelGGL((env_kernel_wide<SC, LP>), wgrid, wblock, h->lds_bytes, st, d, actions, t, *out, reset_only)
-        if (d.scen == CM_PP) { if (d.lpe == 16) CM_WIDE(CM_PP, 16); else if (d.lpe == 32) CM_WIDE(CM_PP, 32); else CM_WIDE(CM_PP, 64); }
-        else { if (d.lpe == 16) CM_WIDE(CM_CO, 16); else if (d.lpe == 32) CM_WIDE(CM_CO, 32); else CM_WIDE(CM_CO, 64); }
+        if (d.scen == CM_PP) CM_WIDE(CM_PP, 64); else CM_WIDE(CM_CO, 64);      // (d.lpe == 64 here)
 #undef CM_WIDE
         CM_HIP(hipGetLastError());
         return CM_OK;

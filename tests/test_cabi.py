@@ -96,3 +96,29 @@ def test_bench_contract_helpers():
     assert abs((b_env + b_pol) - 97.2e3) < 0.5e3                            # config 4: ~97.2 KB
     assert bench.policy_flops(c, 21) == 340224                              # 2N(128d + 39 621 + 192N) at d=21, N=4
     assert bench.host_cores() >= 1
+
+
+def test_env_kernels_use_no_flat_or_scratch_addressing(tmp_path):
+    """Static guard against the one GPU abort on record (round 1, gpurun_out/smoke.log: HSA_STATUS_ERROR_MEMORY_
+    APERTURE_VIOLATION in env_kernel<0>, private_seg_size=88, group_seg_size=288): that fault class
+    can only be raised by FLAT / SCRATCH instructions whose address lands in the LDS or scratch aperture beyond the
+    wave's allocation - `ds_*` accesses out of range are dropped silently.  The env step therefore addresses LDS
+    through integer offsets only (ds ops) and keeps no dynamically indexed local arrays (no scratch): pinned here on
+    the gfx950 ISA of every env kernel instantiation."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "com-marl_amd", "csrc", "cm_env.hip")
+    out = tmp_path / "cm_env.s"
+    subprocess.check_call([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-mllvm",
+                           "-amdgpu-mfma-vgpr-form", "-S", "--cuda-device-only", "-w", "-o", str(out), src])
+    asm = out.read_text()
+    kernels = re.findall(r"\.name:\s+(\S*env_kernel\S*)", asm)
+    assert len(kernels) >= 8, kernels                         # PP / CO x 16 / 32 / 64 lanes + the two wide forms
+    assert not re.search(r"^\s+(flat_(load|store|atomic)|scratch_)", asm, re.M)
+    assert len(re.findall(r"^\s+ds_", asm, re.M)) > 1000
+    for m in re.finditer(r"\.private_segment_fixed_size:\s+(\d+)", asm):
+        assert m.group(1) == "0"
