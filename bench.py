@@ -26,13 +26,13 @@ if ROOT not in sys.path:
 CONFIGS = {
     # BASELINE.json configs[1] - the configuration the metric is quoted on
     "pp_map10": dict(scenario="pp", map=10, sen=1, n_agents=4, n_preys=4, load=2, max_env_steps=200, loss=0.0,
-                     envs=4096, label="PredatorPrey map=10 sen=1 den=0.04 cap=2 (N=M=4), Comm-DP GNN policy"),
+                     envs=4096, step_us=36, label="PredatorPrey map=10 sen=1 den=0.04 cap=2 (N=M=4), Comm-DP GNN policy"),
     "co_map20": dict(scenario="co", map=20, sen=2, n_agents=24, n_preys=0, load=2, max_env_steps=400, loss=0.0,
-                     envs=2048, label="Coverage map=20 sen=2 den=0.06 (N=24), Comm-DP GNN policy"),
+                     envs=2048, step_us=129, label="Coverage map=20 sen=2 den=0.06 (N=24), Comm-DP GNN policy"),
     "pp_map30": dict(scenario="pp", map=30, sen=2, n_agents=72, n_preys=72, load=4, max_env_steps=200, loss=0.0,
-                     envs=1024, label="PredatorPrey map=30 sen=2 den=0.08 cap=4 (N=M=72), Comm-DP GNN policy"),
+                     envs=1024, step_us=250, label="PredatorPrey map=30 sen=2 den=0.08 cap=4 (N=M=72), Comm-DP GNN policy"),
     "co_map30": dict(scenario="co", map=30, sen=2, n_agents=54, n_preys=0, load=2, max_env_steps=400, loss=0.3,
-                     envs=1024, label="Coverage map=30 sen=2 den=0.06 loss=0.3 IID (N=54), Comm-DP GNN policy"),
+                     envs=1024, step_us=203, label="Coverage map=30 sen=2 den=0.06 loss=0.3 IID (N=54), Comm-DP GNN policy"),
 }
 
 
@@ -219,7 +219,15 @@ def main():
         B //= world
     c["envs"] = B
     env = E.GridEnvBatch(c["scenario"], env_params(c), B, device=dev, seed=args.seed, env_id_offset=rank * B)
-    n_streams = args.streams if args.streams is not None else c.get("streams", 2)
+    # env shards per GPU, each with its own policy -> env chain on its own HIP stream.  Two shards pay in steady state
+    # (config 2: 36.4 vs 38.6 us/step; configs 4/5 up to +40 %) because the second shard's chain starts ~100 us after the
+    # first inside every chunk graph and the two stay out of phase; a timed region of a few ms cannot amortise that
+    # start-up stagger (--steps 20 at config 2: 42 us/step as one shard, 45 as two; profiles/r02_steps_sweep.txt), so
+    # short runs use one shard.
+    if args.streams is not None:
+        n_streams = args.streams
+    else:
+        n_streams = 1 if args.steps * c["step_us"] < 10_000 else c.get("streams", 2)
     ns = n_streams if (n_streams > 1 and B % n_streams == 0) else 1
     if ns > 1:      # the same B envs (same global ids, same Philox streams) as `ns` shards, each on its own stream
         shards = [E.GridEnvBatch(c["scenario"], env_params(c), B // ns, device=dev, seed=args.seed,
@@ -230,11 +238,7 @@ def main():
     torch.manual_seed(args.seed)                       # replicas: identical weights on every rank
     policy = make_policy(args.policy, spec, env.N, dev)
     policy.set_rng(args.seed, env_id_offset=rank * B)
-    # steps per captured hipGraph: --chunk, but never more than a quarter of the timed steps - a graph launch submits
-    # all of its ~4 x G kernel nodes before the first one starts (~9 us of host time per step), which a short timed
-    # region would see as dead time in front of its only replay; with >= 4 replays the later ones are enqueued while
-    # the first executes
-    G = max(1, min(args.chunk, -(-args.steps // 4)))
+    G = max(1, min(args.chunk, args.steps))             # steps per captured hipGraph
     eng = RolloutEngine(shards, policy, horizon=G)
     eng.reset()
     use_graph = not args.no_graph

@@ -33,7 +33,7 @@ def _first_episodes(eng, base, T, greedy):
     for t in range(T):
         eng.step(t, greedy=greedy)
     eng.join()
-    eng.step_base.add_(T)
+    eng.bump(T)
     base.batch.check_status()
     pl = eng.path_len[:T]                                                  # [T,B]
     ended = pl > 0

@@ -77,7 +77,9 @@ class RolloutEngine:
         # constant masks are never stored per step (4N^2 [adj != const] rule of SURVEY.md §8d)
         self.dist_adj = None if env.adj_const else z(H + 1, B, N, N)
         self.channels = None if env.ch_const else z(H + 1, B, Lh, N, N)
-        self.step_base = torch.zeros(1, dtype=i32, device=dev)      # device-side Philox counter base (uint32 bits)
+        # device-side Philox counter base of the action sampler (uint32 bits), ONE PER SHARD: every shard bumps its own
+        # copy on its own stream (all copies always hold the same value), so that the shards' chains share nothing
+        self.step_bases = [torch.zeros(1, dtype=i32, device=dev) for _ in self.parts]
         self._graphs = {}
         # fused: eager step() calls use cm_rollout_step (one launch instead of two: the host-bound sampler / eval loops
         # gain; captured chunks keep the two-kernel form, which replays ~2 % faster because the env kernels of one
@@ -88,6 +90,16 @@ class RolloutEngine:
         self._persistent = bool(persistent and fused)
         self._capturing = False
         self.t = 0
+
+    @property
+    def step_base(self):
+        return self.step_bases[0]
+
+    def bump(self, n):
+        """Advance the sampler's Philox counter base by n policy steps (what a chunk does at its end)."""
+        for k, st in enumerate(self.streams):
+            with torch.cuda.stream(st) if st is not None else _null():
+                self.step_bases[k].add_(n)
 
     # ------------------------------------------------------------------------------------------
     def _out(self, t, lo, hi):
@@ -126,7 +138,7 @@ class RolloutEngine:
                 part._out(self._out(t, lo, hi)), greedy=greedy, out_actions=self.actions[t][lo:hi],
                 out_probs=None if self.probs is None else self.probs[t][lo:hi],
                 out_attn=None if self.attn is None else self.attn[t][lo:hi],
-                policy_step=t, step_base=self.step_base, env_id_offset=self.id0 + lo)
+                policy_step=t, step_base=self.step_bases[k], env_id_offset=self.id0 + lo)
             self._fused = ok
             if ok:
                 return
@@ -138,7 +150,7 @@ class RolloutEngine:
             out_probs=None if self.probs is None else self.probs[t][lo:hi],
             out_attn=None if self.attn is None else self.attn[t][lo:hi],
             want_probs=self.probs is not None, want_attn=self.attn is not None,
-            policy_step=t, step_base=self.step_base, env_id_offset=self.id0 + lo)
+            policy_step=t, step_base=self.step_bases[k], env_id_offset=self.id0 + lo)
         part.step_device(self.actions[t][lo:hi], out=self._out(t, lo, hi))
 
     def step(self, t, greedy=False):
@@ -163,14 +175,27 @@ class RolloutEngine:
             if st is not None:
                 cur.wait_stream(st)
 
-    def _wrap(self, n=None):
-        """Carry the last slot written by an n-step chunk into slot 0 (what `obses = next_obses` does)."""
-        n = self.H if n is None else n
-        self.obs[0].copy_(self.obs[n])
+    def _wrap_part(self, k, n):
+        """Carry the last slot written by an n-step chunk into slot 0 for shard k (what `obses = next_obses` does)."""
+        lo, hi = self.bounds[k]
+        self.obs[0][lo:hi].copy_(self.obs[n][lo:hi])
         if self.dist_adj is not None:
-            self.dist_adj[0].copy_(self.dist_adj[n])
+            self.dist_adj[0][lo:hi].copy_(self.dist_adj[n][lo:hi])
         if self.channels is not None:
-            self.channels[0].copy_(self.channels[n])
+            self.channels[0][lo:hi].copy_(self.channels[n][lo:hi])
+
+    def _chunk_part(self, k, n):
+        """Shard k: n steps from slot 0, then its counter bump and its slot-n -> slot-0 carry, all on the current
+        stream (the shard's own): one branch of the captured chunk graph."""
+        for t in range(n):
+            self._step_part(k, t, False)
+        lo, hi = self.bounds[k]
+        pairs = [(b[n][lo:hi], b[0][lo:hi]) for b in (self.obs, self.dist_adj, self.channels) if b is not None]
+        args = []
+        for src, dst in pairs + [(None, None)] * (3 - len(pairs)):
+            args += [L.ptr(src), L.ptr(dst), 0 if src is None else src.numel() * src.element_size()]
+        with torch.cuda.device(self.env.device):            # counter bump + slot n -> slot 0 in one launch
+            L.check(L.lib().cm_chunk_tail(L.ptr(self.step_bases[k]), n, *args, L.current_stream()), "cm_chunk_tail")
 
     def _strides(self):
         e = self.env
@@ -197,7 +222,7 @@ class RolloutEngine:
                     part._out(self._out(t0, lo, hi)), greedy=greedy, out_actions=self.actions[t0][lo:hi],
                     out_probs=None if self.probs is None else self.probs[t0][lo:hi],
                     out_attn=None if self.attn is None else self.attn[t0][lo:hi],
-                    policy_step=t0, step_base=self.step_base, env_id_offset=self.id0 + lo)
+                    policy_step=t0, step_base=self.step_bases[k], env_id_offset=self.id0 + lo)
             if not ok:
                 assert k == 0, "fused chunk availability must not differ between shards"
                 self._fused = False
@@ -207,12 +232,26 @@ class RolloutEngine:
         self._fused = True
         return True
 
+    def _chunk(self, n):
+        """All shards: fork, every shard's n-step chain (+ its tail) on its own stream, join."""
+        self.fork()
+        for k, st in enumerate(self.streams):
+            with torch.cuda.stream(st) if st is not None else _null():
+                self._chunk_part(k, n)
+        self.join()
+
     def prepare_graph(self, n=None):
-        """Capture + instantiate the hipGraph of an n-step chunk (n <= H, default H) WITHOUT advancing the rollout:
-        returns the graph, ready to replay.  One-time host-side setup that must not happen inside a capture (the weight
-        pack, the kernels' hipFuncSetAttribute calls) is triggered by one scratch step whose effects are undone: the
-        env state is snapshotted before and restored after it, and every trajectory slot it wrote is rewritten by the
-        chunk itself.  Call it before a timed region; run_chunk() calls it on first use otherwise."""
+        """Capture + instantiate the hipGraph of an n-step chunk (n <= H, default H) WITHOUT advancing the rollout.
+        One graph holds every shard's chain as a parallel branch (fork ... join).  Measured alternatives
+        (profiles/r02_steps_sweep.txt, config 2): one single-stream graph per shard replayed on the shards' own
+        streams runs 37.7 us/step against 36.4 for the joint graph - independent streams start in phase, so policy
+        kernels meet policy kernels, whereas the joint graph's second branch starts ~100 us (three steps) after the
+        first and the shards stay out of phase; that same stagger is why a SHORT run (bench.py --steps 20) is better
+        off with a single shard.
+        One-time host-side setup that must not happen inside a capture (the weight pack, the kernels'
+        hipFuncSetAttribute calls) is triggered by one scratch step whose effects are undone: the env state is
+        snapshotted before and restored after it, and every trajectory slot it wrote is rewritten by the chunk itself.
+        Call it before a timed region; run_chunk() calls it on first use otherwise."""
         n = self.H if n is None else int(n)
         assert 1 <= n <= self.H
         g = self._graphs.get(n)
@@ -235,13 +274,9 @@ class RolloutEngine:
         g = torch.cuda.CUDAGraph()
         self._capturing = True
         try:
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):   # NCCL's watchdog thread may touch HIP during capture
-                self.fork()
-                for t in range(n):
-                    self.step(t)
-                self.join()
-                self.step_base.add_(n)
-                self._wrap(n)
+            # capture_error_mode: NCCL's watchdog thread may touch HIP during capture
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                self._chunk(n)
         finally:
             self._capturing = False
         self._graphs[n] = g
@@ -249,23 +284,23 @@ class RolloutEngine:
 
     def run_chunk(self, use_graph=True, n=None):
         """n steps (default: the whole horizon H) from slot 0, filling slots 0..n-1 (+ slot n of obs / masks), then
-        carrying slot n into slot 0 and advancing the sampler's Philox base by n: one persistent launch per shard
-        where the library has a fused kernel for the shape and the engine was built with persistent=True; otherwise
-        n x (policy, env) launches - replayed from one hipGraph per chunk length with use_graph.  The graph path and
-        the eager path produce the same trajectory slot by slot (tests/test_hip_ppo_parity.py)."""
+        carrying slot n into slot 0 and advancing the sampler's Philox base by n (cm_chunk_tail, per shard): one
+        persistent launch per shard where the library has a fused kernel for the shape and the engine was built with
+        persistent=True; otherwise n x (policy, env) launches per shard - replayed from one hipGraph per chunk length
+        with use_graph.  The graph path and the eager path produce the same trajectory slot by slot
+        (tests/test_hip_ppo_parity.py)."""
         n = self.H if n is None else int(n)
         assert 1 <= n <= self.H
         if self._persistent and self.steps_fused(0, n):
-            self.step_base.add_(n)
-            self._wrap(n)
+            self.bump(n)
+            self.fork()
+            for k, st in enumerate(self.streams):
+                with torch.cuda.stream(st) if st is not None else _null():
+                    self._wrap_part(k, n)
+            self.join()
             return
         if not use_graph:
-            self.fork()
-            for t in range(n):
-                self.step(t)
-            self.join()
-            self.step_base.add_(n)
-            self._wrap(n)
+            self._chunk(n)
             return
         g = self._graphs.get(n) or self.prepare_graph(n)
         self.policy.sync_weights()          # in-place refresh of the weight pack the graph points at

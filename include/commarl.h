@@ -222,6 +222,15 @@ int cm_rollout_chunk(cm_env_t h, const cm_policy_weights *w, int32_t n_steps, co
                      int32_t env_id_offset, uint32_t policy_step, const uint32_t *policy_step_base, int32_t greedy,
                      int32_t *actions, float *probs, float *attn, const cm_step_out *out, void *stream);
 
+/* End of a chunk of rollout steps, in ONE launch: what the sampler loop does between two steps that a captured chunk
+ * cannot leave to the host - `obses = next_obses` (centralized_ma_on_policy_vectorized_sampler.py:232): the slot the
+ * last step wrote (src) becomes slot 0 (dst) for up to three buffers (observations, dist_adj, channels; bytes multiple
+ * of 4, pointers 4-byte aligned, a NULL / 0-byte entry is skipped) - and the advance of the device-side Philox counter
+ * base of the action sampler by n_steps.  Replaces two framework kernels + a blit per chunk (and the idle gaps
+ * around them) by one kernel of this library. */
+int cm_chunk_tail(uint32_t *policy_step_base, uint32_t n_steps, const void *src0, void *dst0, size_t bytes0,
+                  const void *src1, void *dst1, size_t bytes1, const void *src2, void *dst2, size_t bytes2, void *stream);
+
 /* Plain row-wise MLPs: the non-communicating policies and the Gaussian baseline of the reference's Obs-DP / CENT
  * runners.  Layer l:  y = x . wt[l] + b[l]  (wt TRANSPOSED [in,out] as above), followed by tanh
  * when bit l of tanh_mask is set.  First layer at most 128 outputs; any layer at most 1024. */
