@@ -13,15 +13,28 @@
 
 #include "cm_env_dev.h"
 #include "cm_policy_mfma_dev.h"
+#include "cm_policy_h_dev.h"
 
 namespace cm {
 
-template <int SCEN, int LPE, int KPAD, int MAXMK>
-__global__ __launch_bounds__(mf::TPB) void rollout_step_kernel(mf::FwdArgs a, mf::TrunkW tw, mf::PolHead ph, EnvDev p,
-                                                               cm_rng_tape tape, cm_step_out out, int act_off) {
+bool policy_h_enabled();                                 // cm_policy_h.hip: f16-split dense layers (default) or the all-f32 body
+
+// POL selects the policy body: 0 = cm_policy_mfma_dev.h (all f32), 1 = cm_policy_h_dev.h (f16-split dense layers).  Both
+// forms take the workgroup's dynamic LDS block; `act` = the sampled actions behind the policy tiles.
+template <int POL, int KPAD, int MAXMK>
+__device__ __forceinline__ void policy_body(const mf::FwdArgs &a, const mf::TrunkW &tw, const mf::PolHead &ph, const mh::TrunkH &twh,
+                                            const mh::PolHeadH &phh, float *lds, int32_t *act) {
+    if constexpr (POL == 0) mf::fwd_body<0, KPAD, MAXMK>(a, tw, ph, mf::CritHead{}, lds, blockIdx.x, act);
+    else mh::fwd_body_h<0, KPAD, MAXMK>(a, twh, phh, mh::CritHeadH{}, reinterpret_cast<unsigned char *>(lds), blockIdx.x, act);
+}
+
+template <int SCEN, int LPE, int KPAD, int MAXMK, int POL>
+__global__ __launch_bounds__(mf::TPB) void rollout_step_kernel(mf::FwdArgs a, mf::TrunkW tw, mf::PolHead ph, mh::TrunkH twh,
+                                                               mh::PolHeadH phh, EnvDev p, cm_rng_tape tape, cm_step_out out,
+                                                               int act_off) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     int32_t *act = reinterpret_cast<int32_t *>(lds + act_off);           // [EPB*N] sampled actions, behind the policy tiles
-    mf::fwd_body<0, KPAD, MAXMK>(a, tw, ph, mf::CritHead{}, lds, blockIdx.x, act);
+    policy_body<POL, KPAD, MAXMK>(a, tw, ph, twh, phh, lds, act);
     __syncthreads();                                                     // actions visible; the policy tiles are dead
     const int grp = threadIdx.x / LPE;
     const int envs = min(a.EPB, a.S - (int)blockIdx.x * a.EPB);
@@ -39,9 +52,10 @@ struct ChunkArgs {
     long long obs, actions, probs, attn, reward, reward_f64, done, details, dist_adj, channels, prey_alive, success, path_len;
 };
 
-template <int SCEN, int LPE, int KPAD, int MAXMK>
-__global__ __launch_bounds__(mf::TPB) void rollout_chunk_kernel(mf::FwdArgs a, mf::TrunkW tw, mf::PolHead ph, EnvDev p,
-                                                                cm_step_out out, ChunkArgs c, int act_off) {
+template <int SCEN, int LPE, int KPAD, int MAXMK, int POL>
+__global__ __launch_bounds__(mf::TPB) void rollout_chunk_kernel(mf::FwdArgs a, mf::TrunkW tw, mf::PolHead ph, mh::TrunkH twh,
+                                                                mh::PolHeadH phh, EnvDev p, cm_step_out out, ChunkArgs c,
+                                                                int act_off) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     int32_t *act = reinterpret_cast<int32_t *>(lds + act_off);
     const int grp = threadIdx.x / LPE;
@@ -57,7 +71,7 @@ __global__ __launch_bounds__(mf::TPB) void rollout_chunk_kernel(mf::FwdArgs a, m
         at.actions = a.actions ? a.actions + t * c.actions : nullptr;
         at.probs = a.probs ? a.probs + t * c.probs : nullptr;
         at.attn = a.attn ? a.attn + t * c.attn : nullptr;
-        mf::fwd_body<0, KPAD, MAXMK>(at, tw, ph, mf::CritHead{}, lds, blockIdx.x, act);
+        policy_body<POL, KPAD, MAXMK>(at, tw, ph, twh, phh, lds, act);
         __syncthreads();                                                 // actions visible; the policy tiles are dead
         cm_step_out ot = out;
         if (ot.obs) ot.obs += t * c.obs;
@@ -81,22 +95,24 @@ __global__ __launch_bounds__(mf::TPB) void rollout_chunk_kernel(mf::FwdArgs a, m
     }
 }
 
-template <int SCEN, int LPE, int KPAD, int MAXMK>
-static int launch_fused(mf::FwdArgs a, const mf::TrunkW &tw, const mf::PolHead &ph, const cm_env *h, const cm_rng_tape &t,
-                        const cm_step_out &out, void *stream, const ChunkArgs *chunk = nullptr) {
+template <int SCEN, int LPE, int KPAD, int MAXMK, int POL>
+static int launch_fused(mf::FwdArgs a, const mf::TrunkW &tw, const mf::PolHead &ph, const mh::TrunkH &twh, const mh::PolHeadH &phh,
+                        const cm_env *h, const cm_rng_tape &t, const cm_step_out &out, void *stream, const ChunkArgs *chunk = nullptr) {
     const EnvDev &d = h->dev;
     a.EPB = mf::pick_epb(a.N);
     constexpr int GROUPS = mf::TPB / LPE;
     if (a.EPB > GROUPS) return 1;                                        // more envs per workgroup than env groups
     const int rows_cap = (a.EPB * a.N + 15) & ~15;
-    const size_t pol_floats = mf::lds_floats(rows_cap, a.EPB, a.N);
+    const size_t pol_bytes = POL == 0 ? mf::lds_floats(rows_cap, a.EPB, a.N) * sizeof(float)
+                                      : mh::lds_map(rows_cap, a.EPB, a.N, MAXMK < 0 ? -1 : (MAXMK > 0 ? 1 : 0)).total;
+    const size_t pol_floats = (pol_bytes + 3) / 4;
     const size_t env_bytes = (size_t)d.lds_env * GROUPS;
     if (env_bytes > pol_floats * sizeof(float)) return 1;                // env area would reach into the action array
     const size_t lds = (pol_floats + (size_t)a.EPB * a.N) * sizeof(float);
     if (lds > 160 * 1024) return 1;
     static bool attr_set = false;
     if (!attr_set) {
-        CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_step_kernel<SCEN, LPE, KPAD, MAXMK>),
+        CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_step_kernel<SCEN, LPE, KPAD, MAXMK, POL>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
@@ -104,17 +120,17 @@ static int launch_fused(mf::FwdArgs a, const mf::TrunkW &tw, const mf::PolHead &
     if (chunk) {
         static bool attr_set_c = false;
         if (!attr_set_c) {
-            CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_chunk_kernel<SCEN, LPE, KPAD, MAXMK>),
+            CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_chunk_kernel<SCEN, LPE, KPAD, MAXMK, POL>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr_set_c = true;
         }
-        hipLaunchKernelGGL((rollout_chunk_kernel<SCEN, LPE, KPAD, MAXMK>), dim3(blocks), dim3(mf::TPB), lds, (hipStream_t)stream, a, tw,
-                           ph, d, out, *chunk, (int)pol_floats);
+        hipLaunchKernelGGL((rollout_chunk_kernel<SCEN, LPE, KPAD, MAXMK, POL>), dim3(blocks), dim3(mf::TPB), lds, (hipStream_t)stream, a,
+                           tw, ph, twh, phh, d, out, *chunk, (int)pol_floats);
         CM_HIP(hipGetLastError());
         return CM_OK;
     }
-    hipLaunchKernelGGL((rollout_step_kernel<SCEN, LPE, KPAD, MAXMK>), dim3(blocks), dim3(mf::TPB), lds, (hipStream_t)stream, a, tw, ph,
-                       d, t, out, (int)pol_floats);
+    hipLaunchKernelGGL((rollout_step_kernel<SCEN, LPE, KPAD, MAXMK, POL>), dim3(blocks), dim3(mf::TPB), lds, (hipStream_t)stream, a, tw,
+                       ph, twh, phh, d, t, out, (int)pol_floats);
     CM_HIP(hipGetLastError());
     return CM_OK;
 }
@@ -157,11 +173,26 @@ static int rollout_impl(cm_env_t h, const cm_policy_weights *w, const float *obs
     const int mk = d.N < mk_min ? 0 : (d.N <= 80 ? 25 : 64);                 // as mf::dispatch
     // instantiations: the four BASELINE shapes (PP sen1 small teams; CO sen2 mid teams; PP / CO sen2 large teams)
     const bool quad = d.N == 4 && mf::pick_epb(4) * 4 <= 32;
-    if (d.scen == CM_PP && d.lpe == 16 && kpad == 32 && quad) return launch_fused<CM_PP, 16, 32, -1>(a, tw, ph, h, t, *out, stream, chunk);
-    if (d.scen == CM_PP && d.lpe == 16 && kpad == 32 && mk == 0) return launch_fused<CM_PP, 16, 32, 0>(a, tw, ph, h, t, *out, stream, chunk);
-    if (d.scen == CM_CO && d.lpe == 64 && kpad == 80 && mk == 0) return launch_fused<CM_CO, 64, 80, 0>(a, tw, ph, h, t, *out, stream, chunk);
-    if (d.scen == CM_PP && d.lpe == 64 && kpad == 64 && mk == 25) return launch_fused<CM_PP, 64, 64, 25>(a, tw, ph, h, t, *out, stream, chunk);
-    if (d.scen == CM_CO && d.lpe == 64 && kpad == 80 && mk == 25) return launch_fused<CM_CO, 64, 80, 25>(a, tw, ph, h, t, *out, stream, chunk);
+    const int kh = mh::kh_of(d.d);
+    if (policy_h_enabled() && kh) {                  // f16-split dense layers: the operand pack behind the f32 one
+        const mh::PackLayoutH lh = mh::pack_layout_h(kh, d.L, true);
+        const uint4 *Q = reinterpret_cast<const uint4 *>(P + lo.total);
+        const mh::TrunkH twh{ Q + lh.enc1, w->enc_b1, Q + lh.enc2, w->enc_b2, Q + lh.attn, Q + lh.gcn, w->gcn_b };
+        const mh::PolHeadH phh{ Q + lh.x1, w->hd_b1, Q + lh.h2, w->hd_b2, Q + lh.h3, w->hd_b3, Q + lh.h4, w->hd_b4, w->n_act };
+        if (d.scen == CM_PP && d.lpe == 16 && kh == 32 && quad) return launch_fused<CM_PP, 16, 32, -1, 1>(a, tw, ph, twh, phh, h, t, *out, stream, chunk);
+        if (d.scen == CM_PP && d.lpe == 16 && kh == 32 && mk == 0) return launch_fused<CM_PP, 16, 32, 0, 1>(a, tw, ph, twh, phh, h, t, *out, stream, chunk);
+        if (d.scen == CM_CO && d.lpe == 64 && kh == 96 && mk == 0) return launch_fused<CM_CO, 64, 96, 0, 1>(a, tw, ph, twh, phh, h, t, *out, stream, chunk);
+        if (d.scen == CM_PP && d.lpe == 64 && kh == 64 && mk == 25) return launch_fused<CM_PP, 64, 64, 25, 1>(a, tw, ph, twh, phh, h, t, *out, stream, chunk);
+        if (d.scen == CM_CO && d.lpe == 64 && kh == 96 && mk == 25) return launch_fused<CM_CO, 64, 96, 25, 1>(a, tw, ph, twh, phh, h, t, *out, stream, chunk);
+        return 1;
+    }
+    const mh::TrunkH twh{};
+    const mh::PolHeadH phh{};
+    if (d.scen == CM_PP && d.lpe == 16 && kpad == 32 && quad) return launch_fused<CM_PP, 16, 32, -1, 0>(a, tw, ph, twh, phh, h, t, *out, stream, chunk);
+    if (d.scen == CM_PP && d.lpe == 16 && kpad == 32 && mk == 0) return launch_fused<CM_PP, 16, 32, 0, 0>(a, tw, ph, twh, phh, h, t, *out, stream, chunk);
+    if (d.scen == CM_CO && d.lpe == 64 && kpad == 80 && mk == 0) return launch_fused<CM_CO, 64, 80, 0, 0>(a, tw, ph, twh, phh, h, t, *out, stream, chunk);
+    if (d.scen == CM_PP && d.lpe == 64 && kpad == 64 && mk == 25) return launch_fused<CM_PP, 64, 64, 25, 0>(a, tw, ph, twh, phh, h, t, *out, stream, chunk);
+    if (d.scen == CM_CO && d.lpe == 64 && kpad == 80 && mk == 25) return launch_fused<CM_CO, 64, 80, 25, 0>(a, tw, ph, twh, phh, h, t, *out, stream, chunk);
     return 1;
 }
 

@@ -1,0 +1,158 @@
+// cm_policy_h.hip - launchers and operand pack of the f16-split policy / critic forward (cm_policy_h_dev.h): the dense
+// per-agent layers of CommBaseNet / the policy head / the critic head (reference: comm_base_net.py:80-108,
+// comm_categorical_mlp_policy.py:48-96, comm_base_critic.py:91-114) on v_mfma_f32_16x16x32_f16 with every operand
+// carried as an f16 (hi, 2^12-scaled lo) pair - f32-grade results at a third of the matrix-pipe time of the f32
+// instruction.  Entered from cm_policy_mfma.hip's policy_forward_mfma / critic_forward_mfma; COMMARL_POLICY_KERNEL=f32
+// keeps the all-f32 kernel.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "cm_internal.h"
+#include "cm_rng.h"
+#include "cm_policy_h_dev.h"
+
+namespace cm {
+namespace mh {
+
+template <int HEAD, int KH, int MAXMK, int NW>
+__global__ __launch_bounds__(64 * NW) void fwd_h_kernel(FwdArgs a, TrunkH tw, PolHeadH ph, CritHeadH chd) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_h[];
+    fwd_body_h<HEAD, KH, MAXMK, NW>(a, tw, ph, chd, lds_h, blockIdx.x, nullptr);
+}
+
+template <int HEAD, int KH, int MAXMK, int NW = 4>
+static int launch_h(FwdArgs a, const TrunkH &tw, const PolHeadH &ph, const CritHeadH &chd, void *stream) {
+    a.EPB = mf::pick_epb(a.N);
+    const int rows_cap = (a.EPB * a.N + 15) & ~15;
+    const size_t lds = lds_map(rows_cap, a.EPB, a.N, MAXMK < 0 ? -1 : (MAXMK > 0 ? 1 : 0)).total;
+    if (lds > 160 * 1024) return 1;                      // caller falls back (and reports the size limit there)
+    static bool attr_set = false;
+    if (!attr_set) {
+        CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fwd_h_kernel<HEAD, KH, MAXMK, NW>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const int blocks = (a.S + a.EPB - 1) / a.EPB;
+    hipLaunchKernelGGL((fwd_h_kernel<HEAD, KH, MAXMK, NW>), dim3(blocks), dim3(64 * NW), lds, (hipStream_t)stream, a, tw, ph, chd);
+    CM_HIP(hipGetLastError());
+    return CM_OK;
+}
+
+template <int HEAD>
+static int dispatch_h(const FwdArgs &a, const TrunkH &tw, const PolHeadH &ph, const CritHeadH &chd, void *stream) {
+    const int kh = kh_of(a.d);
+    if (!kh || a.N > 128) return 1;
+    static const int mk_min = [] { const char *e = getenv("COMMARL_MK_MIN"); return e ? atoi(e) : 16; }();
+    const int mk = a.N < mk_min ? 0 : (a.N <= 80 ? 25 : 64);
+    const bool quad = a.N == 4 && mf::pick_epb(4) * 4 <= 32;
+    static const bool w8_on = [] { const char *e = getenv("COMMARL_FWD_WAVES"); return !(e && e[0] == '4'); }();
+    static const int w8_min = [] { const char *e = getenv("COMMARL_FWD_W8MIN"); return e ? atoi(e) : 32; }();
+    const bool w8 = w8_on && a.N >= w8_min;
+#define CM_FWH(K) (quad ? launch_h<HEAD, K, -1>(a, tw, ph, chd, stream) : mk == 0 ? launch_h<HEAD, K, 0>(a, tw, ph, chd, stream) \
+                   : mk == 25 ? (w8 ? launch_h<HEAD, K, 15, 8>(a, tw, ph, chd, stream) : launch_h<HEAD, K, 25>(a, tw, ph, chd, stream)) \
+                              : (w8 ? launch_h<HEAD, K, 32, 8>(a, tw, ph, chd, stream) : launch_h<HEAD, K, 64>(a, tw, ph, chd, stream)))
+    switch (kh) {
+    case 32: return CM_FWH(32);
+    case 64: return CM_FWH(64);
+    case 96: return CM_FWH(96);
+    default: return 1;
+    }
+#undef CM_FWH
+}
+
+// ---- operand pack: Wt [K][OUT] f32 (the ABI's transposed weights) -> A fragments of the transposed layer ----------
+// dst uint4 index ((ct * KB + q) * 2 + plane) * 64 + lane = halves e = 0..7 of W[o = 16 ct + (lane & 15)][k = 32 q + 8 (lane >> 4) + e]
+__global__ void pack_layer_h_kernel(const float *__restrict__ Wt, int K, int OUT, int KB, int CT, uint4 *__restrict__ dst) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;                       // one (ct, q, lane): both planes
+    if (idx >= CT * KB * 64) return;
+    const int lane = idx & 63, blk = idx >> 6, q = blk % KB, ct = blk / KB;
+    const int o = 16 * ct + (lane & 15), k0 = 32 * q + 8 * (lane >> 4);
+    v8h hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = k0 + e;
+        const float w = (k < K && o < OUT) ? Wt[(size_t)k * OUT + o] : 0.0f;
+        h16 h, l;
+        split2(w, h, l);
+        hi[e] = h; lo[e] = l;
+    }
+    dst[((size_t)blk * 2 + 0) * 64 + lane] = __builtin_bit_cast(uint4, hi);
+    dst[((size_t)blk * 2 + 1) * 64 + lane] = __builtin_bit_cast(uint4, lo);
+}
+
+static int pack_one_h(const float *Wt, int K, int OUT, int kp, int out_pad, uint4 *dst, void *stream) {
+    if (!Wt) return set_error(CM_ERR_ARG, "weight pack: null layer weight");
+    const int KB = kp / 32, CT = out_pad / 16, total = CT * KB * 64;
+    hipLaunchKernelGGL(pack_layer_h_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, Wt, K, OUT, KB, CT, dst);
+    CM_HIP(hipGetLastError());
+    return CM_OK;
+}
+
+static int pack_trunk_h(int d, int L, const float *w1t, const float *w2t, const float *wat, const float *gw, int kh,
+                        const PackLayoutH &lo, uint4 *pack, void *stream) {
+    if (int rc = pack_one_h(w1t, d, EH, kh, EH, pack + lo.enc1, stream)) return rc;
+    if (int rc = pack_one_h(w2t, EH, EMB, EH, EMB, pack + lo.enc2, stream)) return rc;
+    if (int rc = pack_one_h(wat, EMB, EMB, EMB, EMB, pack + lo.attn, stream)) return rc;
+    const size_t per = LayerH<EMB, EMB>::PACK_U4;
+    for (int l = 0; l < L; ++l)
+        if (int rc = pack_one_h(gw ? gw + (size_t)l * EMB * EMB : nullptr, EMB, EMB, EMB, EMB, pack + lo.gcn + (size_t)l * per, stream)) return rc;
+    return CM_OK;
+}
+
+}  // namespace mh
+
+// COMMARL_POLICY_KERNEL=f32: the round-1 all-f32 MFMA kernel; anything else (default): the f16-split kernel
+bool policy_h_enabled() {
+    static const bool v = [] { const char *e = getenv("COMMARL_POLICY_KERNEL"); return !(e && e[0] == 'f'); }();
+    return v;
+}
+
+size_t policy_pack_h_bytes(int d, int L, bool policy) {
+    const int kh = mh::kh_of(d);
+    return kh ? mh::pack_layout_h(kh, L, policy).total * sizeof(uint4) : 0;
+}
+
+int policy_pack_h(const cm_policy_weights *w, void *dst, void *stream) {
+    const int kh = mh::kh_of(w->d);
+    if (!kh) return CM_OK;                               // no f16 instantiation for this obs dim: nothing to pack
+    const mh::PackLayoutH lo = mh::pack_layout_h(kh, w->n_hops, true);
+    uint4 *pack = reinterpret_cast<uint4 *>(dst);
+    if (int rc = mh::pack_trunk_h(w->d, w->n_hops, w->enc_w1t, w->enc_w2t, w->attn_wt, w->gcn_w, kh, lo, pack, stream)) return rc;
+    if (int rc = mh::pack_one_h(w->hd_w1t, mf::EMB, mf::H1, mf::EMB, mf::H1, pack + lo.x1, stream)) return rc;
+    if (int rc = mh::pack_one_h(w->hd_w2t, mf::H1, mf::H2, mf::H1, mf::H2, pack + lo.h2, stream)) return rc;
+    if (int rc = mh::pack_one_h(w->hd_w3t, mf::H2, mf::H3, mf::H2, mf::H3, pack + lo.h3, stream)) return rc;
+    return mh::pack_one_h(w->hd_w4t, mf::H3, w->n_act, mf::H3, 16, pack + lo.h4, stream);
+}
+
+int critic_pack_h(const cm_critic_weights *w, void *dst, void *stream) {
+    const int kh = mh::kh_of(w->d);
+    if (!kh) return CM_OK;
+    const mh::PackLayoutH lo = mh::pack_layout_h(kh, w->n_hops, false);
+    uint4 *pack = reinterpret_cast<uint4 *>(dst);
+    if (int rc = mh::pack_trunk_h(w->d, w->n_hops, w->enc_w1t, w->enc_w2t, w->attn_wt, w->gcn_w, kh, lo, pack, stream)) return rc;
+    return mh::pack_one_h(w->dec_w1t, mf::EMB, mf::DH, mf::EMB, mf::DH, pack + lo.x1, stream);
+}
+
+// h_pack = the f16 operand pack (behind the f32 one in the caller's pack buffer).  Returns 1 when this shape has no
+// f16 instantiation (the caller then runs the f32 kernel).
+int policy_forward_h(const cm_policy_weights *w, const void *h_pack, mf::FwdArgs a, void *stream) {
+    const int kh = mh::kh_of(w->d);
+    if (!kh || !h_pack) return 1;
+    const mh::PackLayoutH lo = mh::pack_layout_h(kh, w->n_hops, true);
+    const uint4 *P = reinterpret_cast<const uint4 *>(h_pack);
+    const mh::TrunkH tw{ P + lo.enc1, w->enc_b1, P + lo.enc2, w->enc_b2, P + lo.attn, P + lo.gcn, w->gcn_b };
+    const mh::PolHeadH ph{ P + lo.x1, w->hd_b1, P + lo.h2, w->hd_b2, P + lo.h3, w->hd_b3, P + lo.h4, w->hd_b4, w->n_act };
+    return mh::dispatch_h<0>(a, tw, ph, mh::CritHeadH{}, stream);
+}
+
+int critic_forward_h(const cm_critic_weights *w, const void *h_pack, mf::FwdArgs a, void *stream) {
+    const int kh = mh::kh_of(w->d);
+    if (!kh || !h_pack) return 1;
+    const mh::PackLayoutH lo = mh::pack_layout_h(kh, w->n_hops, false);
+    const uint4 *P = reinterpret_cast<const uint4 *>(h_pack);
+    const mh::TrunkH tw{ P + lo.enc1, w->enc_b1, P + lo.enc2, w->enc_b2, P + lo.attn, P + lo.gcn, w->gcn_b };
+    const mh::CritHeadH chd{ P + lo.x1, w->dec_b1, w->dec_w2t, w->dec_b2 };
+    return mh::dispatch_h<1>(a, tw, mh::PolHeadH{}, chd, stream);
+}
+
+}  // namespace cm

@@ -1,0 +1,768 @@
+// cm_policy_h_dev.h - fused Comm-DP policy / critic forward with the dense per-agent layers on the gfx950 f16 matrix
+// pipe, at f32 accuracy: every operand x is carried as TWO f16 planes
+//        hi = f16(x)              lo = f16((x - hi) * 2^12)            x = hi + 2^-12 lo  (error <= 2^-22 |x|)
+// and a 16x16x32 block of a product costs THREE v_mfma_f32_16x16x32_f16 (hi.hi, hi.lo, lo.hi; the cross terms have
+// their own accumulators and are scaled by 2^-12 once, in the epilogue; the dropped lo.lo term is 2^-24 relative)
+// instead of EIGHT v_mfma_f32_16x16x4_f32.  Measured on MI355X (tools/micro/layer_split_schemes.hip, 32 rows x 128 -> 64,
+// tanh, chained layers, two workgroups per CU): 1871 clk per layer against 3678, max |error| against an f64 reference
+// 3.4e-7 against 7.0e-7 for the f32 MFMA form (the f16 instruction accumulates its 32 products more accurately than a
+// chain of eight f32 MFMAs does) - far inside the 1e-5 parity bar, and pinned by the reference fixtures.
+//
+// Same computation, arguments and LDS-resident structure as cm_policy_mfma_dev.h (reference:
+// comm_categorical_mlp_policy.py:48-119, comm_base_net.py:80-108, attention_module.py:26-51,
+// graph_conv_module.py:51-72, comm_base_critic.py:91-114); what changes:
+//   * TRANSPOSED formulation of every dense layer: D[feature][row] = sum_k W[feature][k] X[row][k].  The weights are
+//     the A operand (registers, fetched from the operand pack as 16-byte fragments), the activations the B operand -
+//     8 consecutive k of one row = one ds_read_b128 per plane - and a lane's four D values are four CONSECUTIVE
+//     features of one row: the epilogue (bias, tanh, split) ends in one ds_write_b64 per plane.
+//   * activations live in LDS as f16 plane pairs [row][K + 8] (row stride == 4 words mod 32: the 16 rows of a
+//     quarter-wave's b128 read land on distinct bank groups); f32 copies exist only where a non-dense consumer needs
+//     them (H.Wg for the aggregation, the logits, and E / Q for the small-team VALU attention).
+//   * the N x N products of large teams (scores, aggregation) read the same planes: scores on the f16 pipe as well,
+//     the aggregation (K = N, f32 attention weights) stays on v_mfma_f32_16x16x4_f32 with swapped operands so that it
+//     too ends in four consecutive features per lane.
+// COMMARL_POLICY_KERNEL=f32 selects the round-1 all-f32 kernel (cm_policy_mfma_dev.h) for A/B runs.
+#pragma once
+#include "cm_policy_mfma_dev.h"
+
+namespace cm {
+namespace mh {
+
+using mf::FwdArgs;
+using mf::CritHead;
+using mf::EH; using mf::EMB; using mf::H1; using mf::H2; using mf::H3; using mf::DH; using mf::MAX_ACT;
+using mf::v4f;
+using mf::fast_tanh;
+using mf::lds_barrier;
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef _Float16 v4h __attribute__((ext_vector_type(4)));
+typedef _Float16 h16;
+
+constexpr float LO_SCALE = 4096.0f, LO_INV = 1.0f / 4096.0f;
+constexpr int SHP = 8;                                  // halves of padding per plane row
+constexpr int SF = 68;                                  // f32 row stride (words) of the 64-wide f32 tiles (as mf::SE)
+
+__host__ __device__ inline void split2(float x, h16 &h, h16 &l) {
+    h = (h16)x;
+    l = (h16)((x - (float)h) * LO_SCALE);
+}
+__device__ __forceinline__ float join2(h16 h, h16 l) { return fmaf((float)l, LO_INV, (float)h); }
+
+// A pair of f16 planes [rows][stride halves] in LDS
+struct Planes {
+    h16 *hi, *lo;
+    int stride;                                         // halves; (stride / 2) % 32 == 4
+};
+__device__ __forceinline__ Planes planes_at(void *base, int rows_cap, int K) {
+    Planes p;
+    p.stride = K + SHP;
+    p.hi = reinterpret_cast<h16 *>(base);
+    p.lo = p.hi + (size_t)rows_cap * p.stride;
+    return p;
+}
+__host__ __device__ inline size_t planes_bytes(int rows_cap, int K) { return (size_t)rows_cap * (K + SHP) * 2 * sizeof(h16); }
+
+// weight pointers into the f16 operand pack; biases stay plain f32
+struct TrunkH { const uint4 *enc1_p; const float *enc_b1; const uint4 *enc2_p; const float *enc_b2; const uint4 *attn_p, *gcn_p; const float *gcn_b; };
+struct PolHeadH { const uint4 *h1_p; const float *b1; const uint4 *h2_p; const float *b2; const uint4 *h3_p; const float *b3; const uint4 *h4_p; const float *b4; int n_act; };
+struct CritHeadH { const uint4 *d1_p; const float *b1; const float *w2t, *b2; };
+
+enum { OUT_PLANES = 1, OUT_F32 = 2 };
+
+// One dense layer, transposed:  out[row][o] = act(bias[o] + sum_k in[row][k] * W[o][k]),  o < OUT, k < KP (zero padded).
+// load() pulls this wave's A fragments (its 16-feature tiles, all k blocks, both planes) one layer AHEAD of run().
+// Pack layout (pack_layer_h_kernel): uint4 index ((ct * KB + q) * 2 + plane) * 64 + lane = the 8 halves
+// W[16 ct + (lane & 15)][32 q + 8 (lane >> 4) + e].
+template <int KP, int OUT, int NW = 4>
+struct LayerH {
+    static_assert(KP % 32 == 0 && OUT % 16 == 0, "f16 layers are built from 16x16x32 blocks");
+    static constexpr int CT = OUT / 16;
+    static constexpr int NCT = CT >= NW ? CT / NW : 1;
+    static constexpr int KB = KP / 32;
+    static constexpr size_t PACK_U4 = (size_t)CT * KB * 2 * 64;
+    v8h wh[NCT][KB], wl[NCT][KB];
+    float bv[NCT][4];
+
+    __device__ __forceinline__ void load(const uint4 *__restrict__ P, const float *__restrict__ bias, int wave, int lane,
+                                         int out_real = OUT) {
+        const int ct0 = CT >= NW ? wave * NCT : (wave % CT);
+        const int g = lane >> 4;
+#pragma unroll
+        for (int t = 0; t < NCT; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = (ct0 + t) * 16 + 4 * g + r;
+                bv[t][r] = (bias && o < out_real) ? bias[o] : 0.0f;
+            }
+#pragma unroll
+            for (int q = 0; q < KB; ++q) {
+                const uint4 a = P[(((size_t)(ct0 + t) * KB + q) * 2 + 0) * 64 + lane];
+                const uint4 b = P[(((size_t)(ct0 + t) * KB + q) * 2 + 1) * 64 + lane];
+                wh[t][q] = __builtin_bit_cast(v8h, a);
+                wl[t][q] = __builtin_bit_cast(v8h, b);
+            }
+        }
+    }
+
+    // in: planes; outputs: planes (OUT_PLANES) and / or f32 [row][fstride] (OUT_F32).  Rows of a tile that lie beyond
+    // `rows` hold zeros on input and receive finite garbage, exactly as in the f32 kernel.
+    template <bool TANH, int OUTS>
+    __device__ __forceinline__ void run(const Planes in, const Planes out, float *fout, int fstride, int row_tiles, int wave,
+                                        int lane) const {
+        const int ct0 = CT >= NW ? wave * NCT : (wave % CT);
+        const int rt_start = CT >= NW ? 0 : wave / CT;
+        const int rt_step = CT >= NW ? 1 : NW / CT;
+        const int c = lane & 15, g = lane >> 4;
+        for (int rt = rt_start; rt < row_tiles; rt += 2 * rt_step) {
+            const int rtB = rt + rt_step;
+            const bool hasB = rtB < row_tiles;
+            const int row0 = rt * 16 + c, row1 = (hasB ? rtB : rt) * 16 + c;
+            const v8h *ph0 = reinterpret_cast<const v8h *>(in.hi + (size_t)row0 * in.stride + 8 * g);
+            const v8h *pl0 = reinterpret_cast<const v8h *>(in.lo + (size_t)row0 * in.stride + 8 * g);
+            const v8h *ph1 = reinterpret_cast<const v8h *>(in.hi + (size_t)row1 * in.stride + 8 * g);
+            const v8h *pl1 = reinterpret_cast<const v8h *>(in.lo + (size_t)row1 * in.stride + 8 * g);
+            v8h xh0[KB], xl0[KB], xh1[KB], xl1[KB];
+#pragma unroll
+            for (int q = 0; q < KB; ++q) { xh0[q] = ph0[4 * q]; xl0[q] = pl0[4 * q]; xh1[q] = ph1[4 * q]; xl1[q] = pl1[4 * q]; }
+            // three independent accumulators per (feature tile, row tile): hi.hi (+ bias), hi.lo, lo.hi
+            v4f hh0[NCT], ca0[NCT], cb0[NCT], hh1[NCT], ca1[NCT], cb1[NCT];
+#pragma unroll
+            for (int t = 0; t < NCT; ++t) {
+                hh0[t] = (v4f){ bv[t][0], bv[t][1], bv[t][2], bv[t][3] };
+                hh1[t] = hh0[t];
+                ca0[t] = cb0[t] = ca1[t] = cb1[t] = (v4f){ 0.f, 0.f, 0.f, 0.f };
+            }
+#define CM_MFH(A, B, ACC) ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, ACC, 0, 0, 0)
+            if (hasB) {
+#pragma unroll
+                for (int q = 0; q < KB; ++q)
+#pragma unroll
+                    for (int t = 0; t < NCT; ++t) {
+                        CM_MFH(wh[t][q], xh0[q], hh0[t]); CM_MFH(wh[t][q], xh1[q], hh1[t]);
+                        CM_MFH(wh[t][q], xl0[q], ca0[t]); CM_MFH(wh[t][q], xl1[q], ca1[t]);
+                        CM_MFH(wl[t][q], xh0[q], cb0[t]); CM_MFH(wl[t][q], xh1[q], cb1[t]);
+                    }
+            } else {
+#pragma unroll
+                for (int q = 0; q < KB; ++q)
+#pragma unroll
+                    for (int t = 0; t < NCT; ++t) {
+                        CM_MFH(wh[t][q], xh0[q], hh0[t]); CM_MFH(wh[t][q], xl0[q], ca0[t]); CM_MFH(wl[t][q], xh0[q], cb0[t]);
+                    }
+            }
+#undef CM_MFH
+            // D layout: lane (c, g) holds features 16 ct + 4 g + r (r = 0..3) of row (row tile) * 16 + c
+#pragma unroll
+            for (int t = 0; t < NCT; ++t) {
+                const int f0 = (ct0 + t) * 16 + 4 * g;
+                float y0[4], y1[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v0 = fmaf(ca0[t][r] + cb0[t][r], LO_INV, hh0[t][r]);
+                    y0[r] = TANH ? fast_tanh(v0) : v0;
+                    const float v1 = fmaf(ca1[t][r] + cb1[t][r], LO_INV, hh1[t][r]);
+                    y1[r] = TANH ? fast_tanh(v1) : v1;
+                }
+                if (OUTS & OUT_F32) {
+                    *reinterpret_cast<float4 *>(fout + (size_t)row0 * fstride + f0) = make_float4(y0[0], y0[1], y0[2], y0[3]);
+                    if (hasB) *reinterpret_cast<float4 *>(fout + (size_t)row1 * fstride + f0) = make_float4(y1[0], y1[1], y1[2], y1[3]);
+                }
+                if (OUTS & OUT_PLANES) {
+                    v4h oh, ol;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { h16 h, l; split2(y0[r], h, l); oh[r] = h; ol[r] = l; }
+                    *reinterpret_cast<v4h *>(out.hi + (size_t)row0 * out.stride + f0) = oh;
+                    *reinterpret_cast<v4h *>(out.lo + (size_t)row0 * out.stride + f0) = ol;
+                    if (hasB) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { h16 h, l; split2(y1[r], h, l); oh[r] = h; ol[r] = l; }
+                        *reinterpret_cast<v4h *>(out.hi + (size_t)row1 * out.stride + f0) = oh;
+                        *reinterpret_cast<v4h *>(out.lo + (size_t)row1 * out.stride + f0) = ol;
+                    }
+                }
+            }
+        }
+    }
+};
+
+// scores[i][j] = sum_k Q[i][k] E[j][k] over K = 64 of one 16 x 16 tile pair, on the f16 pipe from the plane pairs:
+// A operand = 8 consecutive k of Q row (ra), B operand = 8 consecutive k of E row (rb).  D: lane (c, g) holds
+// rows 4g + r of column c - the layout of the f32 instruction, so everything downstream is unchanged.
+__device__ __forceinline__ v4f scores_tile_h(const Planes Q, const Planes E, int ra, int rb, int g) {
+    const v8h *qh = reinterpret_cast<const v8h *>(Q.hi + (size_t)ra * Q.stride + 8 * g);
+    const v8h *ql = reinterpret_cast<const v8h *>(Q.lo + (size_t)ra * Q.stride + 8 * g);
+    const v8h *eh = reinterpret_cast<const v8h *>(E.hi + (size_t)rb * E.stride + 8 * g);
+    const v8h *el = reinterpret_cast<const v8h *>(E.lo + (size_t)rb * E.stride + 8 * g);
+    v8h a0 = qh[0], a1 = qh[4], al0 = ql[0], al1 = ql[4], b0 = eh[0], b1 = eh[4], bl0 = el[0], bl1 = el[4];
+    v4f hh = (v4f){ 0.f, 0.f, 0.f, 0.f }, ca = hh, cb = hh;
+    hh = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0, hh, 0, 0, 0);
+    ca = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bl0, ca, 0, 0, 0);
+    cb = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, b0, cb, 0, 0, 0);
+    hh = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, hh, 0, 0, 0);
+    ca = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bl1, ca, 0, 0, 0);
+    cb = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, b1, cb, 0, 0, 0);
+    v4f sc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sc[r] = fmaf(ca[r] + cb[r], LO_INV, hh[r]);
+    return sc;
+}
+
+// stage the observation tile [RT*16][KH] into planes (zero k-padding, zero padded rows)
+template <int KH, int TPBW>
+__device__ __forceinline__ void stage_obs(const FwdArgs &a, const Planes X, int s0, int rows, int RT, int tid) {
+    const float *src = a.obs + (size_t)s0 * a.N * a.d;
+    const int total = RT * 16 * KH;
+    for (int k = tid; k < total; k += TPBW) {
+        const int r = k / KH, f = k - r * KH;
+        const float v = (r < rows && f < a.d) ? src[(size_t)r * a.d + f] : 0.0f;
+        h16 h, l;
+        split2(v, h, l);
+        X.hi[(size_t)r * X.stride + f] = h;
+        X.lo[(size_t)r * X.stride + f] = l;
+    }
+}
+
+// ---- LDS map (bytes), shared by every path; regions that are never live together overlay each other -------------
+//   R1  planes 128 wide  : enc1 output, then the A tile of the aggregation (f32 [rows][NPA]), then head layer 1 output
+//   EP  planes 64 wide   : E
+//   HP  planes 64 wide   : H_l  (the observation planes overlay HP..T before the encoder has run)
+//   T   288 B per row    : Q planes | H.Wg f32 [rows][SF] | head layer 2 output planes
+//   EF  f32 [rows][SF]   : E in f32 - small-team VALU attention only (0 bytes otherwise)
+//   QF  f32 [rows][SF]   : Q in f32 - small-team VALU attention only
+//   M   f32 [EPB*N][NP]  : scores / attention (0 bytes on the teams-of-4 path)
+//   rs  f32 [rows]       : critic per-agent values
+struct LdsMap { size_t r1, ep, hp, t, ef, qf, m, rs, total; };
+__host__ __device__ inline LdsMap lds_map(int rows_cap, int epb, int N, int mode /* -1 quad, 0 small, >0 big */) {
+    LdsMap o;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 15) & ~(size_t)15; return at; };
+    o.r1 = take(planes_bytes(rows_cap, 128));
+    o.ep = take(planes_bytes(rows_cap, 64));
+    o.hp = take(planes_bytes(rows_cap, 64));
+    o.t = take(planes_bytes(rows_cap, 64));
+    o.ef = take(mode == 0 ? (size_t)rows_cap * SF * 4 : 0);
+    o.qf = take(mode == 0 ? (size_t)rows_cap * SF * 4 : 0);
+    o.m = take(mode < 0 ? 0 : (size_t)epb * N * (N | 1) * 4);
+    o.rs = take((size_t)rows_cap * 4);
+    o.total = off;
+    return o;
+}
+
+// HEAD 0 = policy, 1 = critic; KH = obs dim rounded up to 32; MAXMK as in mf::fwd_body (-1 teams of 4, 0 small teams on
+// the VALU, > 0 large teams on MFMA tiles); NW = waves per workgroup
+template <int HEAD, int KH, int MAXMK, int NW = 4>
+__device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, const PolHeadH &ph, const CritHeadH &chd,
+                                           unsigned char *lds, int blk, int32_t *act_lds) {
+    constexpr int TPBW = 64 * NW, NG = 4 * NW;
+    static_assert(NW == 4 || (NW == 8 && MAXMK > 0), "8-wave workgroups are built for the large-team path only");
+    constexpr bool quad_path = MAXMK < 0;
+    constexpr bool big = MAXMK > 0;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int N = a.N, L = a.L, NN = N * N, NP = N | 1;
+    const int s0 = blk * a.EPB;
+    const int envs = min(a.EPB, a.S - s0);
+    const int rows = envs * N, rows_cap = (a.EPB * N + 15) & ~15, RT = (rows + 15) >> 4;
+    const LdsMap lm = lds_map(rows_cap, a.EPB, N, quad_path ? -1 : (big ? 1 : 0));
+    const Planes Ap = planes_at(lds + lm.r1, rows_cap, 128);
+    const Planes Ep = planes_at(lds + lm.ep, rows_cap, 64);
+    const Planes Hp = planes_at(lds + lm.hp, rows_cap, 64);
+    const Planes Tp = planes_at(lds + lm.t, rows_cap, 64);
+    const Planes Xp = planes_at(lds + lm.hp, rows_cap, KH);     // over HP (+ T for KH = 96): dead before either is written
+    float *HW = reinterpret_cast<float *>(lds + lm.t);          // [rows_cap][SF] (272 B per row <= the 288 of the planes)
+    float *EF = reinterpret_cast<float *>(lds + lm.ef);
+    float *QF = reinterpret_cast<float *>(lds + lm.qf);
+    float *M = reinterpret_cast<float *>(lds + lm.m);
+    float *rs = reinterpret_cast<float *>(lds + lm.rs);
+    float *Amat = reinterpret_cast<float *>(lds + lm.r1);       // [rows][NPA] f32, NPA <= 132
+    const Planes Gp = planes_at(lds + lm.ep, rows_cap, 32);     // head layer 3 output (32 wide) over EP: E is dead by then
+    float *LG = reinterpret_cast<float *>(lds + lm.t);          // logits f32 [rows_cap][20] over T (head layer 2 output is
+    constexpr int SLG = 20;                                     // consumed before they are written - see the barriers)
+
+    // ---- weights one layer ahead, observation tile first (vector-memory results return in issue order) ----
+    stage_obs<KH, TPBW>(a, Xp, s0, rows, RT, tid);
+    LayerH<KH, EH, NW> l_enc1;
+    l_enc1.load(tw.enc1_p, tw.enc_b1, wave, lane);
+    LayerH<EH, EMB, NW> l_enc2;
+    l_enc2.load(tw.enc2_p, tw.enc_b2, wave, lane);
+    const uint32_t draw_step = a.policy_step + (a.step_base ? *a.step_base : 0u);
+    lds_barrier();
+    if (a.stop == 1) return;
+    l_enc1.template run<true, OUT_PLANES>(Xp, Ap, nullptr, 0, RT, wave, lane);
+    LayerH<EMB, EMB, NW> l_sq;                               // 64 x 64 square layers: attention, then (non-quad) the hops
+    l_sq.load(tw.attn_p, nullptr, wave, lane);
+    LayerH<EMB, EMB, NW> l_g;                                // quad path: GCN weights, one hop ahead
+    if (quad_path && L > 0) l_g.load(tw.gcn_p, nullptr, wave, lane);
+    lds_barrier();
+    if (a.stop == 2) return;
+    if (quad_path || big) l_enc2.template run<true, OUT_PLANES>(Ap, Ep, nullptr, 0, RT, wave, lane);
+    else l_enc2.template run<true, OUT_PLANES | OUT_F32>(Ap, Ep, EF, SF, RT, wave, lane);
+    LayerH<EMB, HEAD == 0 ? H1 : DH, NW> l_x1;               // first head layer (policy 64 -> 128, critic 64 -> 64)
+    LayerH<H1, H2, NW> l_h2;
+    if (quad_path) l_x1.load(HEAD == 0 ? ph.h1_p : chd.d1_p, HEAD == 0 ? ph.b1 : chd.b1, wave, lane);
+    lds_barrier();
+    if (a.stop == 3) return;
+
+    if (quad_path) {
+        // ---- teams of 4: attention and aggregation in registers (see cm_policy_mfma_dev.h for the layout argument) ----
+        const int c = lane & 15, g = lane >> 4, q = lane & 3;
+        const bool diag = (c >> 2) == g;
+        l_sq.template run<false, OUT_PLANES>(Ep, Tp, nullptr, 0, RT, wave, lane);           // Q = E.Wa^T  -> planes in T
+        float *HW0 = reinterpret_cast<float *>(lds + lm.r1);                               // H.Wg_l f32: hop parity picks the
+        float *HW1 = HW0 + (size_t)rows_cap * SF;                                           // half of R1 (enc1 output is dead)
+        if (L > 0) {
+            l_g.template run<false, OUT_F32>(Ep, Ep, HW0, SF, RT, wave, lane);             // H.Wg_0 (hop 0 reads E)
+            if (L > 1) l_g.load(tw.gcn_p + LayerH<EMB, EMB, NW>::PACK_U4, nullptr, wave, lane);
+        }
+        if (HEAD == 0) l_h2.load(ph.h2_p, ph.b2, wave, lane);
+        lds_barrier();
+        if (a.stop == 4) return;
+        const int tw_ = (RT > 1) ? (wave & 1) : 0, ch = wave >> 1;
+        const int rb = 16 * tw_;
+        const v4f sc = scores_tile_h(Tp, Ep, rb + c, rb + c, g);
+        float m[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float ex = __builtin_amdgcn_exp2f((sc[r] - mf::quad_max(sc[r])) * 1.4426950408889634f);
+            m[r] = ex * __builtin_amdgcn_rcpf(mf::quad_sum(ex));
+        }
+        if (a.stop == 42) return;
+        const int env_l = 4 * tw_ + g;
+        const bool live = diag && env_l < envs;
+        const size_t env_g = (size_t)s0 + min(env_l, envs - 1);
+        if (a.attn && ch == 0 && live) {
+            float *dst = a.attn + env_g * 16 + q;
+            dst[0] = m[0]; dst[4] = m[1]; dst[8] = m[2]; dst[12] = m[3];
+        }
+        if (a.stop == 5) return;
+        for (int l = 0; l < L; ++l) {
+            const float *HWl = (l & 1) ? HW1 : HW0;
+            const bool last = l == L - 1;
+            float v[4], w[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                                // A = M * Range * Chan_l (comm_base_net.py:101)
+                float x = m[r];
+                if (a.adj) x *= a.adj[env_g * 16 + 4 * r + q];
+                if (a.chan) x *= a.chan[(env_g * L + l) * 16 + 4 * r + q];
+                v[r] = x * __builtin_amdgcn_rcpf(mf::quad_sum(x) + 1e-12f);  // :102-103
+            }
+            mf::quad_transpose(v, q, w);
+            // swapped operands: D'[feature][row] = sum_k HW[k][feature] A[row][k]; lane (c, g) ends up with features
+            // 32 ch + 16 t + 4 g + r of row rb + c
+            v4f acc[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[t][r] = tw.gcn_b ? tw.gcn_b[(size_t)l * EMB + 32 * ch + 16 * t + 4 * g + r] : 0.0f;
+            }
+            float hb[2][4];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) hb[t][j] = HWl[(size_t)(rb + 4 * g + j) * SF + 32 * ch + 16 * t + c];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float aop = diag ? w[j] : 0.0f;
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(hb[0][j], aop, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(hb[1][j], aop, acc[1], 0, 0, 0);
+            }
+            if (RT > 1 || (wave & 1) == 0) {                              // single-tile workgroups: odd waves duplicate tile 0
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int f0 = 32 * ch + 16 * t + 4 * g;
+                    const size_t o = (size_t)(rb + c) * Hp.stride + f0;
+                    v4h eh, el;
+                    if (last && !a.no_residual) {
+                        eh = *reinterpret_cast<const v4h *>(Ep.hi + (size_t)(rb + c) * Ep.stride + f0);
+                        el = *reinterpret_cast<const v4h *>(Ep.lo + (size_t)(rb + c) * Ep.stride + f0);
+                    }
+                    v4h oh, ol;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float hv = fast_tanh(acc[t][r]);                 // graph_conv_module.py:65-70
+                        if (last && !a.no_residual) hv += join2(eh[r], el[r]);   // policy :74-77
+                        h16 h, lo_; split2(hv, h, lo_); oh[r] = h; ol[r] = lo_;
+                    }
+                    *reinterpret_cast<v4h *>(Hp.hi + o) = oh;
+                    *reinterpret_cast<v4h *>(Hp.lo + o) = ol;
+                }
+            }
+            lds_barrier();
+            if (a.stop == 61 + l) return;
+            if (!last) {
+                l_g.template run<false, OUT_F32>(Hp, Hp, (l & 1) ? HW0 : HW1, SF, RT, wave, lane);     // H.Wg_{l+1}
+                if (l + 2 < L) l_g.load(tw.gcn_p + (size_t)(l + 2) * LayerH<EMB, EMB, NW>::PACK_U4, nullptr, wave, lane);
+                lds_barrier();
+            }
+        }
+    } else {
+        // ---- general teams ----
+        if (HEAD == 0 && !big) l_h2.load(ph.h2_p, ph.b2, wave, lane);
+        if (big) l_sq.template run<false, OUT_PLANES>(Ep, Tp, nullptr, 0, RT, wave, lane);      // Q -> planes in T
+        else l_sq.template run<false, OUT_F32>(Ep, Ep, QF, SF, RT, wave, lane);                 // Q -> f32 (VALU scores)
+        if (L > 0) l_sq.load(tw.gcn_p, nullptr, wave, lane);
+        lds_barrier();
+        if (a.stop == 4) return;
+        if (big) {
+            {   // scores on the f16 pipe: 16 x 16 tiles dealt round-robin to waves
+                const int c = lane & 15, g = lane >> 4, NT = (N + 15) >> 4, per_env = NT * NT;
+                for (int t = wave; t < envs * per_env; t += NW) {
+                    const int e = t / per_env, rc = t - e * per_env, rt = rc / NT, ct = rc - rt * NT;
+                    const int ra = e * N + min(rt * 16 + c, N - 1), rbb = e * N + min(ct * 16 + c, N - 1);
+                    const v4f sc = scores_tile_h(Tp, Ep, ra, rbb, g);
+                    const int j = ct * 16 + c;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = rt * 16 + 4 * g + r;
+                        if (i < N && j < N) M[(size_t)(e * N + i) * NP + j] = sc[r];
+                    }
+                }
+            }
+            lds_barrier();
+            if (a.stop == 41) return;
+            for (int r0 = 0; r0 < rows; r0 += NG) {   // 16 lanes per matrix row, DPP row reductions
+                const int r = min(r0 + (tid >> 4), rows - 1), sl = tid & 15;
+                float *m = M + (size_t)r * NP;
+                float mx = -INFINITY;
+                for (int j = sl; j < N; j += 16) mx = fmaxf(mx, m[j]);
+                mx = mf::row16_max(mx);
+                float sum = 0.0f;
+                for (int j = sl; j < N; j += 16) { const float ex = __builtin_amdgcn_exp2f((m[j] - mx) * 1.4426950408889634f); sum += ex; if (r0 + (tid >> 4) < rows) m[j] = ex; }
+                sum = mf::row16_sum(sum);
+                const float rsum = __builtin_amdgcn_rcpf(sum);
+                if (r0 + (tid >> 4) < rows)
+                    for (int j = sl; j < N; j += 16) m[j] = m[j] * rsum;
+            }
+        } else {
+            for (int k = tid; k < envs * NN; k += TPBW) {
+                const int e = k / NN, ij = k - e * NN, i = ij / N, j = ij - i * N;
+                const float4 *qv = reinterpret_cast<const float4 *>(QF + (size_t)(e * N + i) * SF);
+                const float4 *cv = reinterpret_cast<const float4 *>(EF + (size_t)(e * N + j) * SF);
+                float acc = 0.0f;
+#pragma unroll
+                for (int kk = 0; kk < EMB / 4; ++kk) {
+                    const float4 x = qv[kk], y = cv[kk];
+                    acc = fmaf(x.x, y.x, acc); acc = fmaf(x.y, y.y, acc); acc = fmaf(x.z, y.z, acc); acc = fmaf(x.w, y.w, acc);
+                }
+                M[(size_t)(e * N + i) * NP + j] = acc;
+            }
+            lds_barrier();
+            for (int r = tid; r < rows; r += TPBW) {
+                float *m = M + (size_t)r * NP;
+                float mx = -INFINITY, sum = 0.0f;
+                for (int j = 0; j < N; ++j) mx = fmaxf(mx, m[j]);
+                for (int j = 0; j < N; ++j) { const float ex = expf(m[j] - mx); m[j] = ex; sum += ex; }
+                for (int j = 0; j < N; ++j) m[j] = m[j] / sum;
+            }
+        }
+        lds_barrier();
+        if (a.stop == 42) return;
+        if (a.attn) {
+            float *dst = a.attn + (size_t)s0 * NN;
+            if (big) {
+                for (int r = tid >> 4; r < rows; r += NG)
+                    for (int j = tid & 15; j < N; j += 16) dst[(size_t)r * N + j] = M[(size_t)r * NP + j];
+            } else {
+                for (int k = tid; k < envs * NN; k += TPBW) { const int r = k / N, j = k - r * N; dst[k] = M[(size_t)r * NP + j]; }
+            }
+        }
+        if (a.stop == 5) return;
+        for (int l = 0; l < L; ++l) {
+            const Planes Hin = (l == 0) ? Ep : Hp;
+            const bool last = l == L - 1;
+            constexpr int JB = (MAXMK == 25 || MAXMK == 15) ? 5 : 8;
+            float mk[MAXMK > 0 ? MAXMK : 1];
+            const bool masked = a.adj || a.chan;
+            if (MAXMK > 0 && masked) {
+                const int gq = tid >> 4, sl = tid & 15;
+#pragma unroll
+                for (int qq = 0; qq < MAXMK; ++qq) {
+                    const int r = (qq / JB) * NG + gq, j = (qq % JB) * 16 + sl;
+                    float v = 1.0f;
+                    if (r < rows && j < N) {
+                        const int e = envs == 1 ? 0 : r / N, i = r - e * N;
+                        const size_t off = (size_t)i * N + j;
+                        if (a.adj) v = a.adj[(size_t)(s0 + e) * NN + off];
+                        if (a.chan) v *= a.chan[((size_t)(s0 + e) * L + l) * NN + off];
+                    }
+                    mk[qq] = v;
+                }
+            }
+            l_sq.template run<false, OUT_F32>(Hin, Hin, HW, SF, RT, wave, lane);                // H.Wg_l -> f32 in T
+            if (a.stop == 61 + l) return;
+            if (l + 1 < L) l_sq.load(tw.gcn_p + (size_t)(l + 1) * LayerH<EMB, EMB, NW>::PACK_U4, nullptr, wave, lane);
+            if (MAXMK > 0 && big) {
+                const int NPA = (((N + 15) >> 4) << 4) + 4;
+                {   // A row = M row * mask, renormalised: 16 lanes per row, DPP row sum, one pass
+                    const int gq = tid >> 4, sl = tid & 15;
+#pragma unroll
+                    for (int rbk = 0; rbk < MAXMK / JB; ++rbk) {
+                        const int r = rbk * NG + gq;
+                        if (rbk * NG < rows) {
+                            const bool lv = r < rows;
+                            const float *mr = M + (size_t)(lv ? r : 0) * NP;
+                            float v[JB];
+                            float sum = 0.0f;
+#pragma unroll
+                            for (int jb = 0; jb < JB; ++jb) {
+                                const int j = jb * 16 + sl;
+                                v[jb] = (lv && j < N) ? mr[j] * (masked ? mk[rbk * JB + jb] : 1.0f) : 0.0f;
+                                sum += v[jb];
+                            }
+                            const float rden = __builtin_amdgcn_rcpf(mf::row16_sum(sum) + 1e-12f);
+                            if (lv) {
+                                float *ar = Amat + (size_t)r * NPA;
+#pragma unroll
+                                for (int jb = 0; jb < JB; ++jb) { const int j = jb * 16 + sl; if (j < NPA) ar[j] = j < N ? v[jb] * rden : 0.0f; }
+                            }
+                        }
+                    }
+                }
+                lds_barrier();
+                if (a.stop == 51 + l) return;
+                {   // aggregation on v_mfma_f32_16x16x4_f32 with swapped operands: D'[feature][row] = sum_k HW[k][feature] A[row][k].
+                    // Wave w owns features 16 (w & 3) .. +15; with 8 waves two waves share them and split the row tiles.
+                    constexpr int MAXKS = 32;
+                    const int c = lane & 15, g = lane >> 4, NT = (N + 15) >> 4, KQ = NT;
+                    const int colA = (wave & 3) * 16 + c;                 // feature this lane supplies as the A operand
+                    const int f0 = (wave & 3) * 16 + 4 * g;               // first of the four features this lane ends up with
+                    const int rt0 = 2 * (wave >> 2), rt_stride = 2 * (NW >> 2);
+                    float bvr[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bvr[r] = tw.gcn_b ? tw.gcn_b[(size_t)l * EMB + f0 + r] : 0.0f;
+                    for (int e = 0; e < envs; ++e) {
+                        float b[MAXKS];
+#pragma unroll
+                        for (int kk = 0; kk < MAXKS; ++kk) {
+                            const int k = 16 * (kk >> 2) + 4 * g + (kk & 3);
+                            b[kk] = (kk < 4 * KQ && k < N) ? HW[(size_t)(e * N + k) * SF + colA] : 0.0f;
+                        }
+                        for (int rt = rt0; rt < NT; rt += rt_stride) {
+                            const bool hasB = rt + 1 < NT;
+                            const int ra = min(rt * 16 + c, N - 1), rb2 = min((hasB ? rt + 1 : rt) * 16 + c, N - 1);
+                            const float4 *pa = reinterpret_cast<const float4 *>(Amat + (size_t)(e * N + ra) * NPA + 4 * g);
+                            const float4 *pb = reinterpret_cast<const float4 *>(Amat + (size_t)(e * N + rb2) * NPA + 4 * g);
+                            float4 xa[MAXKS / 4], xb[MAXKS / 4];
+#pragma unroll
+                            for (int kq = 0; kq < MAXKS / 4; ++kq) {
+                                const int kc = kq < KQ ? kq : KQ - 1;
+                                xa[kq] = pa[4 * kc]; xb[kq] = pb[4 * kc];
+                            }
+                            v4f acc0 = (v4f){ bvr[0], bvr[1], bvr[2], bvr[3] }, acc1 = acc0;
+#pragma unroll
+                            for (int kq = 0; kq < MAXKS / 4; ++kq) {
+                                if (kq < KQ) {
+                                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b[4 * kq + 0], xa[kq].x, acc0, 0, 0, 0);
+                                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b[4 * kq + 0], xb[kq].x, acc1, 0, 0, 0);
+                                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b[4 * kq + 1], xa[kq].y, acc0, 0, 0, 0);
+                                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b[4 * kq + 1], xb[kq].y, acc1, 0, 0, 0);
+                                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b[4 * kq + 2], xa[kq].z, acc0, 0, 0, 0);
+                                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b[4 * kq + 2], xb[kq].z, acc1, 0, 0, 0);
+                                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b[4 * kq + 3], xa[kq].w, acc0, 0, 0, 0);
+                                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b[4 * kq + 3], xb[kq].w, acc1, 0, 0, 0);
+                                }
+                            }
+                            // lane (c, g): features f0 .. f0+3 of rows rt*16 + c and (rt+1)*16 + c
+#pragma unroll
+                            for (int half = 0; half < 2; ++half) {
+                                const int i = (rt + half) * 16 + c;
+                                if ((half == 0 || hasB) && i < N) {
+                                    const size_t row = (size_t)(e * N + i);
+                                    v4h eh, el, oh, ol;
+                                    if (last && !a.no_residual) {
+                                        eh = *reinterpret_cast<const v4h *>(Ep.hi + row * Ep.stride + f0);
+                                        el = *reinterpret_cast<const v4h *>(Ep.lo + row * Ep.stride + f0);
+                                    }
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) {
+                                        float hv = fast_tanh(half == 0 ? acc0[r] : acc1[r]);
+                                        if (last && !a.no_residual) hv += join2(eh[r], el[r]);
+                                        h16 h, lo_; split2(hv, h, lo_); oh[r] = h; ol[r] = lo_;
+                                    }
+                                    *reinterpret_cast<v4h *>(Hp.hi + row * Hp.stride + f0) = oh;
+                                    *reinterpret_cast<v4h *>(Hp.lo + row * Hp.stride + f0) = ol;
+                                }
+                            }
+                        }
+                    }
+                }
+                lds_barrier();
+                continue;
+            }
+            // small teams (VALU): masked + renormalised rows of A, then A.(HW) per (row, feature)
+            if (N <= 16) {
+                for (int r = tid; r < rows; r += TPBW) {
+                    const int e = r / N, i = r - e * N;
+                    const float *mr = M + (size_t)r * NP;
+                    float *ar = Amat + (size_t)r * NP;
+                    float sum = 0.0f;
+                    for (int j = 0; j < N; ++j) {
+                        float v = mr[j];
+                        if (a.adj) v *= a.adj[(size_t)(s0 + e) * NN + i * N + j];
+                        if (a.chan) v *= a.chan[((size_t)(s0 + e) * L + l) * NN + i * N + j];
+                        ar[j] = v; sum += v;
+                    }
+                    const float den = sum + 1e-12f;
+                    for (int j = 0; j < N; ++j) ar[j] = ar[j] / den;
+                }
+            } else {
+                for (int k = tid; k < envs * NN; k += TPBW) {
+                    const int e = k / NN, ij = k - e * NN, r = k / N, j = k - r * N;
+                    float v = M[(size_t)r * NP + j];
+                    if (a.adj) v *= a.adj[(size_t)(s0 + e) * NN + ij];
+                    if (a.chan) v *= a.chan[((size_t)(s0 + e) * L + l) * NN + ij];
+                    Amat[(size_t)r * NP + j] = v;
+                }
+                lds_barrier();
+                for (int r = tid; r < rows; r += TPBW) {
+                    float *ar = Amat + (size_t)r * NP;
+                    float sum = 0.0f;
+                    for (int j = 0; j < N; ++j) sum += ar[j];
+                    const float den = sum + 1e-12f;
+                    for (int j = 0; j < N; ++j) ar[j] = ar[j] / den;
+                }
+            }
+            lds_barrier();
+            {
+                const int o = tid & (EMB - 1), rg = tid >> 6;
+                const float bvv = tw.gcn_b ? tw.gcn_b[(size_t)l * EMB + o] : 0.0f;
+                for (int r0 = rg * 4; r0 < rows; r0 += 4 * NW) {
+                    const int e = r0 / N;
+                    const float *hw = HW + (size_t)e * N * SF + o;
+                    float acc[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+                    const float *ar[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) ar[i] = Amat + (size_t)min(r0 + i, rows - 1) * NP;
+                    for (int j = 0; j < N; ++j) {
+                        const float h = hw[(size_t)j * SF];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[i] = fmaf(ar[i][j], h, acc[i]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (r0 + i < rows && (r0 + i) / N == e) {
+                            float hv = fast_tanh(acc[i] + bvv);
+                            if (last && !a.no_residual) hv += EF[(size_t)(r0 + i) * SF + o];
+                            h16 h, lo_; split2(hv, h, lo_);
+                            Hp.hi[(size_t)(r0 + i) * Hp.stride + o] = h;
+                            Hp.lo[(size_t)(r0 + i) * Hp.stride + o] = lo_;
+                        }
+                }
+            }
+            lds_barrier();
+        }
+    }
+    if (a.stop == 6) return;
+    // ---- no hops: embeddings[-1] is E itself, so x = E + E with the residual (:74-77), else E ----
+    if (L == 0) {
+        const float f = a.no_residual ? 1.0f : 2.0f;
+        for (int k = tid; k < rows * EMB; k += TPBW) {
+            const int r = k >> 6, o = k & 63;
+            const float e = join2(Ep.hi[(size_t)r * Ep.stride + o], Ep.lo[(size_t)r * Ep.stride + o]);
+            h16 h, lo_; split2(f * e, h, lo_);
+            Hp.hi[(size_t)r * Hp.stride + o] = h; Hp.lo[(size_t)r * Hp.stride + o] = lo_;
+        }
+        lds_barrier();
+    }
+
+    if (!quad_path) l_x1.load(HEAD == 0 ? ph.h1_p : chd.d1_p, HEAD == 0 ? ph.b1 : chd.b1, wave, lane);
+    if (HEAD == 0) {
+        if (big) l_h2.load(ph.h2_p, ph.b2, wave, lane);
+        LayerH<H2, H3, NW> l_h3;
+        l_h3.load(ph.h3_p, ph.b3, wave, lane);
+        l_x1.template run<true, OUT_PLANES>(Hp, Ap, nullptr, 0, RT, wave, lane);             // 64 -> 128 into R1
+        lds_barrier();
+        l_h2.template run<true, OUT_PLANES>(Ap, Tp, nullptr, 0, RT, wave, lane);             // 128 -> 64 into T
+        const int A = ph.n_act;
+        LayerH<H3, 16, NW> l_h4;                             // 32 -> n_act (<= 8) logits, zero-padded to one feature tile
+        l_h4.load(ph.h4_p, ph.b4, wave, lane, A);
+        lds_barrier();
+        l_h3.template run<true, OUT_PLANES>(Tp, Gp, nullptr, 0, RT, wave, lane);             // 64 -> 32 into EP
+        lds_barrier();
+        if (a.stop == 7) return;
+        l_h4.template run<false, OUT_F32>(Gp, Gp, LG, SLG, RT, wave, lane);                  // logits f32 into T
+        lds_barrier();
+        for (int r = tid; r < rows; r += TPBW) {
+            float lg[MAX_ACT], p[MAX_ACT];
+            const float *x = LG + (size_t)r * SLG;
+#pragma unroll
+            for (int cc = 0; cc < MAX_ACT; ++cc) lg[cc] = (cc < A) ? x[cc] : 0.0f;
+            float mx = -INFINITY, sum = 0.0f, msum = 0.0f;
+#pragma unroll
+            for (int cc = 0; cc < MAX_ACT; ++cc) if (cc < A) mx = fmaxf(mx, lg[cc]);
+#pragma unroll
+            for (int cc = 0; cc < MAX_ACT; ++cc) if (cc < A) { p[cc] = __builtin_amdgcn_exp2f((lg[cc] - mx) * 1.4426950408889634f); sum += p[cc]; }
+            const size_t grow = (size_t)s0 * N + r;
+            const float rsum = __builtin_amdgcn_rcpf(sum);
+#pragma unroll
+            for (int cc = 0; cc < MAX_ACT; ++cc) if (cc < A) {
+                const float av = a.avail ? a.avail[grow * A + cc] : 1.0f;
+                p[cc] = (p[cc] * rsum) * av; msum += p[cc];
+            }
+            const float rmsum = __builtin_amdgcn_rcpf(msum);
+#pragma unroll
+            for (int cc = 0; cc < MAX_ACT; ++cc) if (cc < A) p[cc] = p[cc] * rmsum;
+            if (a.probs) {
+#pragma unroll
+                for (int cc = 0; cc < MAX_ACT; ++cc) if (cc < A) a.probs[grow * A + cc] = p[cc];
+            }
+            if (a.actions || act_lds) {
+                int act = 0;
+                if (a.greedy) {
+                    float best = p[0];
+#pragma unroll
+                    for (int cc = 1; cc < MAX_ACT; ++cc) if (cc < A && p[cc] > best) { best = p[cc]; act = cc; }
+                } else {
+                    const int e = r / N, i = r - e * N;
+                    const u32x4 xr = philox4x32_10((uint32_t)(a.env_id_offset + s0 + e), draw_step, SITE_ACTION, (uint32_t)i,
+                                                   a.key0, a.key1);
+                    const float u = unit_f32(xr.x);
+                    float acc = 0.0f;
+                    int sel = -1, lastc = 0;
+#pragma unroll
+                    for (int cc = 0; cc < MAX_ACT; ++cc) if (cc < A) { if (p[cc] > 0.0f) lastc = cc; acc += p[cc]; if (sel < 0 && u < acc) sel = cc; }
+                    act = sel < 0 ? lastc : sel;
+                }
+                if (a.actions) a.actions[grow] = act;
+                if (act_lds) act_lds[r] = act;
+            }
+        }
+    } else {
+        float *XF = reinterpret_cast<float *>(lds + lm.r1);                                  // critic: tanh(x1) f32 [rows][SF] in R1
+        l_x1.template run<true, OUT_F32>(Hp, Hp, XF, SF, RT, wave, lane);
+        lds_barrier();
+        for (int r = tid; r < rows; r += TPBW) {
+            const float *x = XF + (size_t)r * SF;
+            float acc = chd.b2 ? chd.b2[0] : 0.0f;
+            for (int k = 0; k < DH; ++k) acc = fmaf(x[k], chd.w2t[k], acc);
+            rs[r] = acc;
+        }
+        lds_barrier();
+        for (int e = tid; e < envs; e += TPBW) {
+            float v = 0.0f;
+            for (int i = 0; i < N; ++i) v += rs[e * N + i];
+            a.values[s0 + e] = v;
+        }
+    }
+}
+
+// ---- host-side helpers ----
+inline int kh_of(int d) { const int k = (d + 31) & ~31; return (k == 32 || k == 64 || k == 96) ? k : 0; }
+struct PackLayoutH { size_t enc1, enc2, attn, gcn, x1, h2, h3, h4, total; };      // offsets in uint4 (16-byte) units
+inline PackLayoutH pack_layout_h(int kh, int L, bool policy) {
+    PackLayoutH o{};
+    size_t off = 0;
+    auto lay = [&](int K, int OUT) { const size_t at = off; off += (size_t)(OUT / 16) * (K / 32) * 2 * 64; return at; };
+    o.enc1 = lay(kh, EH);
+    o.enc2 = lay(EH, EMB);
+    o.attn = lay(EMB, EMB);
+    o.gcn = off;
+    for (int l = 0; l < L; ++l) lay(EMB, EMB);
+    o.x1 = policy ? lay(EMB, H1) : lay(EMB, DH);
+    if (policy) { o.h2 = lay(H1, H2); o.h3 = lay(H2, H3); o.h4 = lay(H3, 16); }
+    o.total = off;
+    return o;
+}
+
+}  // namespace mh
+}  // namespace cm

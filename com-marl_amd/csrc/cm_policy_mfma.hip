@@ -144,6 +144,14 @@ static int pack_trunk(int d, int L, const float *w1t, const float *w2t, const fl
 
 }  // namespace mf
 
+// cm_policy_h.hip: the f16-split kernel (default) and its operand pack, stored BEHIND the f32 pack in the caller's buffer
+bool policy_h_enabled();
+size_t policy_pack_h_bytes(int d, int L, bool policy);
+int policy_pack_h(const cm_policy_weights *w, void *dst, void *stream);
+int critic_pack_h(const cm_critic_weights *w, void *dst, void *stream);
+int policy_forward_h(const cm_policy_weights *w, const void *h_pack, mf::FwdArgs a, void *stream);
+int critic_forward_h(const cm_critic_weights *w, const void *h_pack, mf::FwdArgs a, void *stream);
+
 bool policy_shape_ok(const cm_policy_weights *w) {
     return w && w->enc_hidden == mf::EH && w->emb == mf::EMB && w->h1 == mf::H1 && w->h2 == mf::H2 && w->h3 == mf::H3 &&
            w->n_act >= 1 && w->n_act <= mf::MAX_ACT && w->n_agents >= 1 && w->n_agents <= 128 && w->n_hops >= 0 &&
@@ -170,6 +178,10 @@ int policy_forward_mfma(const cm_policy_weights *w, int32_t S, const float *obs,
     { const char *e = getenv("COMMARL_FWD_STOP"); a.stop = e ? atoi(e) : 0; }
     const mf::PackLayout lo = mf::pack_layout(mf::kpad_of(w->d), w->n_hops, true);
     const float *P = w->mfma_pack;
+    if (policy_h_enabled()) {
+        const int rc = policy_forward_h(w, P + lo.total, a, stream);
+        if (rc <= 0) return rc;
+    }
     mf::TrunkW tw{ P + lo.enc1, w->enc_b1, P + lo.enc2, w->enc_b2, P + lo.attn, P + lo.gcn, w->gcn_b };
     mf::PolHead ph{ P + lo.x1, w->hd_b1, P + lo.h2, w->hd_b2, P + lo.h3, w->hd_b3, P + lo.h4, w->hd_b4, w->n_act };
     return mf::dispatch<0>(a, tw, ph, mf::CritHead{}, stream);
@@ -183,6 +195,10 @@ int critic_forward_mfma(const cm_critic_weights *w, int32_t S, const float *obs,
     a.obs = obs; a.adj = adj; a.chan = chan; a.values = values; a.no_residual = w->no_residual;
     const mf::PackLayout lo = mf::pack_layout(mf::kpad_of(w->d), w->n_hops, false);
     const float *P = w->mfma_pack;
+    if (policy_h_enabled()) {
+        const int rc = critic_forward_h(w, P + lo.total, a, stream);
+        if (rc <= 0) return rc;
+    }
     mf::TrunkW tw{ P + lo.enc1, w->enc_b1, P + lo.enc2, w->enc_b2, P + lo.attn, P + lo.gcn, w->gcn_b };
     mf::CritHead chd{ P + lo.x1, w->dec_b1, w->dec_w2t, w->dec_b2 };
     return mf::dispatch<1>(a, tw, mf::PolHead{}, chd, stream);
@@ -192,7 +208,7 @@ int critic_forward_mfma(const cm_critic_weights *w, int32_t S, const float *obs,
 
 extern "C" size_t cm_policy_pack_bytes(const cm_policy_weights *w) {
     if (!cm::policy_shape_ok(w)) return 0;
-    return cm::mf::pack_layout(cm::mf::kpad_of(w->d), w->n_hops, true).total * sizeof(float);
+    return cm::mf::pack_layout(cm::mf::kpad_of(w->d), w->n_hops, true).total * sizeof(float) + cm::policy_pack_h_bytes(w->d, w->n_hops, true);
 }
 
 extern "C" int cm_policy_pack(const cm_policy_weights *w, float *pack, void *stream) {
@@ -205,12 +221,13 @@ extern "C" int cm_policy_pack(const cm_policy_weights *w, float *pack, void *str
     if (int rc = mf::pack_one(w->hd_w1t, mf::EMB, mf::H1, mf::EMB, mf::H1, pack + lo.x1, stream)) return rc;
     if (int rc = mf::pack_one(w->hd_w2t, mf::H1, mf::H2, mf::H1, mf::H2, pack + lo.h2, stream)) return rc;
     if (int rc = mf::pack_one(w->hd_w3t, mf::H2, mf::H3, mf::H2, mf::H3, pack + lo.h3, stream)) return rc;
-    return mf::pack_one(w->hd_w4t, mf::H3, w->n_act, mf::H3, 16, pack + lo.h4, stream);
+    if (int rc = mf::pack_one(w->hd_w4t, mf::H3, w->n_act, mf::H3, 16, pack + lo.h4, stream)) return rc;
+    return policy_pack_h(w, pack + lo.total, stream);          // the f16 (hi, lo) fragments, behind the f32 ones
 }
 
 extern "C" size_t cm_critic_pack_bytes(const cm_critic_weights *w) {
     if (!cm::critic_shape_ok(w)) return 0;
-    return cm::mf::pack_layout(cm::mf::kpad_of(w->d), w->n_hops, false).total * sizeof(float);
+    return cm::mf::pack_layout(cm::mf::kpad_of(w->d), w->n_hops, false).total * sizeof(float) + cm::policy_pack_h_bytes(w->d, w->n_hops, false);
 }
 
 extern "C" int cm_critic_pack(const cm_critic_weights *w, float *pack, void *stream) {
@@ -220,5 +237,6 @@ extern "C" int cm_critic_pack(const cm_critic_weights *w, float *pack, void *str
     const int kpad = mf::kpad_of(w->d);
     const mf::PackLayout lo = mf::pack_layout(kpad, w->n_hops, false);
     if (int rc = mf::pack_trunk(w->d, w->n_hops, w->enc_w1t, w->enc_w2t, w->attn_wt, w->gcn_w, kpad, lo, pack, stream)) return rc;
-    return mf::pack_one(w->dec_w1t, mf::EMB, mf::DH, mf::EMB, mf::DH, pack + lo.x1, stream);
+    if (int rc = mf::pack_one(w->dec_w1t, mf::EMB, mf::DH, mf::EMB, mf::DH, pack + lo.x1, stream)) return rc;
+    return critic_pack_h(w, pack + lo.total, stream);
 }
