@@ -42,9 +42,16 @@ constexpr float LO_SCALE = 4096.0f, LO_INV = 1.0f / 4096.0f;
 constexpr int SHP = 8;                                  // halves of padding per plane row
 constexpr int SF = 68;                                  // f32 row stride (words) of the 64-wide f32 tiles (as mf::SE)
 
+#ifndef CM_H_VARIANT
+#define CM_H_VARIANT 0          // experiment bits: 1 = cross terms share one accumulator, 2 = residual as one fma
+#endif
 __host__ __device__ inline void split2(float x, h16 &h, h16 &l) {
     h = (h16)x;
+#if (CM_H_VARIANT & 2)
+    l = (h16)fmaf(-(float)h, LO_SCALE, x * LO_SCALE);   // exact: both products are exact, so is their difference
+#else
     l = (h16)((x - (float)h) * LO_SCALE);
+#endif
 }
 __device__ __forceinline__ float join2(h16 h, h16 l) { return fmaf((float)l, LO_INV, (float)h); }
 
@@ -133,6 +140,27 @@ struct LayerH {
                 ca0[t] = cb0[t] = ca1[t] = cb1[t] = (v4f){ 0.f, 0.f, 0.f, 0.f };
             }
 #define CM_MFH(A, B, ACC) ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, ACC, 0, 0, 0)
+#if (CM_H_VARIANT & 1)
+            if (hasB) {
+#pragma unroll
+                for (int q = 0; q < KB; ++q) {
+#pragma unroll
+                    for (int t = 0; t < NCT; ++t) { CM_MFH(wh[t][q], xh0[q], hh0[t]); CM_MFH(wh[t][q], xh1[q], hh1[t]); }
+#pragma unroll
+                    for (int t = 0; t < NCT; ++t) { CM_MFH(wh[t][q], xl0[q], ca0[t]); CM_MFH(wh[t][q], xl1[q], ca1[t]); }
+#pragma unroll
+                    for (int t = 0; t < NCT; ++t) { CM_MFH(wl[t][q], xh0[q], ca0[t]); CM_MFH(wl[t][q], xh1[q], ca1[t]); }
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < KB; ++q) {
+#pragma unroll
+                    for (int t = 0; t < NCT; ++t) { CM_MFH(wh[t][q], xh0[q], hh0[t]); CM_MFH(wh[t][q], xl0[q], ca0[t]); }
+#pragma unroll
+                    for (int t = 0; t < NCT; ++t) CM_MFH(wl[t][q], xh0[q], ca0[t]);
+                }
+            }
+#else
             if (hasB) {
 #pragma unroll
                 for (int q = 0; q < KB; ++q)
@@ -150,6 +178,7 @@ struct LayerH {
                         CM_MFH(wh[t][q], xh0[q], hh0[t]); CM_MFH(wh[t][q], xl0[q], ca0[t]); CM_MFH(wl[t][q], xh0[q], cb0[t]);
                     }
             }
+#endif
 #undef CM_MFH
             // D layout: lane (c, g) holds features 16 ct + 4 g + r (r = 0..3) of row (row tile) * 16 + c
 #pragma unroll
@@ -183,6 +212,66 @@ struct LayerH {
             }
         }
     }
+
+    // The GCN weight product H.Wg in the NON-transposed formulation D[row][feature] = sum_k X[row][k] W[feature][k]:
+    // the same fragments with the MFMA operands swapped.  Lane (c, g) then holds rows 16 rt + 4 g + r of feature
+    // 16 ct + c - four consecutive SOURCE rows of one feature - and writes them k-contiguously into the per-env
+    // transposed planes HWt[env][feature][k = row - env * N] (kstride halves per feature), the layout the aggregation's
+    // A operand reads with one ds_read_b128 per 8 source rows.  Rows beyond `rows` are not written; the k-padding
+    // [N, Kp) of every feature row is zeroed once by the caller.
+    __device__ __forceinline__ void run_hwt(const Planes in, h16 *hwt_hi, h16 *hwt_lo, int kstride, int N, int rows, int envs,
+                                            int row_tiles, int wave, int lane) const {
+        const int ct0 = CT >= NW ? wave * NCT : (wave % CT);
+        const int rt_start = CT >= NW ? 0 : wave / CT;
+        const int rt_step = CT >= NW ? 1 : NW / CT;
+        const int c = lane & 15, g = lane >> 4;
+        for (int rt = rt_start; rt < row_tiles; rt += 2 * rt_step) {
+            const int rtB = rt + rt_step;
+            const bool hasB = rtB < row_tiles;
+            const int row0 = rt * 16 + c, row1 = (hasB ? rtB : rt) * 16 + c;
+            const v8h *ph0 = reinterpret_cast<const v8h *>(in.hi + (size_t)row0 * in.stride + 8 * g);
+            const v8h *pl0 = reinterpret_cast<const v8h *>(in.lo + (size_t)row0 * in.stride + 8 * g);
+            const v8h *ph1 = reinterpret_cast<const v8h *>(in.hi + (size_t)row1 * in.stride + 8 * g);
+            const v8h *pl1 = reinterpret_cast<const v8h *>(in.lo + (size_t)row1 * in.stride + 8 * g);
+            v8h xh0[KB], xl0[KB], xh1[KB], xl1[KB];
+#pragma unroll
+            for (int q = 0; q < KB; ++q) { xh0[q] = ph0[4 * q]; xl0[q] = pl0[4 * q]; xh1[q] = ph1[4 * q]; xl1[q] = pl1[4 * q]; }
+            v4f hh0[NCT], cr0[NCT], hh1[NCT], cr1[NCT];
+#pragma unroll
+            for (int t = 0; t < NCT; ++t) hh0[t] = hh1[t] = cr0[t] = cr1[t] = (v4f){ 0.f, 0.f, 0.f, 0.f };
+#define CM_MFH(A, B, ACC) ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, ACC, 0, 0, 0)
+#pragma unroll
+            for (int q = 0; q < KB; ++q) {
+#pragma unroll
+                for (int t = 0; t < NCT; ++t) { CM_MFH(xh0[q], wh[t][q], hh0[t]); if (hasB) CM_MFH(xh1[q], wh[t][q], hh1[t]); }
+#pragma unroll
+                for (int t = 0; t < NCT; ++t) { CM_MFH(xl0[q], wh[t][q], cr0[t]); if (hasB) CM_MFH(xl1[q], wh[t][q], cr1[t]); }
+#pragma unroll
+                for (int t = 0; t < NCT; ++t) { CM_MFH(xh0[q], wl[t][q], cr0[t]); if (hasB) CM_MFH(xh1[q], wl[t][q], cr1[t]); }
+            }
+#undef CM_MFH
+#pragma unroll
+            for (int t = 0; t < NCT; ++t) {
+                const int f = (ct0 + t) * 16 + c;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int r0 = (half == 0 ? rt : rtB) * 16 + 4 * g;          // four consecutive rows, never straddling envs (N % 4 == 0 or one env)
+                    if ((half == 0 || hasB) && r0 < rows) {
+                        const int e = envs == 1 ? 0 : r0 / N, k = r0 - e * N;
+                        v4h oh, ol;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float y = half == 0 ? fmaf(cr0[t][r], LO_INV, hh0[t][r]) : fmaf(cr1[t][r], LO_INV, hh1[t][r]);
+                            h16 h, l; split2((r0 + r < rows) ? y : 0.0f, h, l); oh[r] = h; ol[r] = l;
+                        }
+                        const size_t o = ((size_t)e * EMB + f) * kstride + k;
+                        *reinterpret_cast<v4h *>(hwt_hi + o) = oh;
+                        *reinterpret_cast<v4h *>(hwt_lo + o) = ol;
+                    }
+                }
+            }
+        }
+    }
 };
 
 // scores[i][j] = sum_k Q[i][k] E[j][k] over K = 64 of one 16 x 16 tile pair, on the f16 pipe from the plane pairs:
@@ -207,18 +296,47 @@ __device__ __forceinline__ v4f scores_tile_h(const Planes Q, const Planes E, int
     return sc;
 }
 
-// stage the observation tile [RT*16][KH] into planes (zero k-padding, zero padded rows)
+// stage the observation tile [RT*16][KH] into planes (zero k-padding, zero padded rows).  A 16-lane group takes a row,
+// its lanes stride the features (coalesced 64-byte segments, no division by the runtime obs dim); every load of the
+// tile is issued before the first is consumed - the loop below is fully unrolled up to MAXR row rounds, so the global
+// latency is paid once, not once per round.
 template <int KH, int TPBW>
 __device__ __forceinline__ void stage_obs(const FwdArgs &a, const Planes X, int s0, int rows, int RT, int tid) {
+    constexpr int NGR = TPBW / 16, FB = KH / 16, MAXR = 3;       // row groups, feature blocks, unrolled row rounds
     const float *src = a.obs + (size_t)s0 * a.N * a.d;
-    const int total = RT * 16 * KH;
-    for (int k = tid; k < total; k += TPBW) {
-        const int r = k / KH, f = k - r * KH;
-        const float v = (r < rows && f < a.d) ? src[(size_t)r * a.d + f] : 0.0f;
-        h16 h, l;
-        split2(v, h, l);
-        X.hi[(size_t)r * X.stride + f] = h;
-        X.lo[(size_t)r * X.stride + f] = l;
+    const int gq = tid >> 4, sl = tid & 15, nrow = RT * 16;
+    float v[MAXR][FB];
+#pragma unroll
+    for (int rr = 0; rr < MAXR; ++rr) {
+        const int r = rr * NGR + gq;
+#pragma unroll
+        for (int fb = 0; fb < FB; ++fb) {
+            const int f = fb * 16 + sl;
+            v[rr][fb] = (r < rows && f < a.d) ? src[(size_t)r * a.d + f] : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int rr = 0; rr < MAXR; ++rr) {
+        const int r = rr * NGR + gq;
+        if (r < nrow) {
+#pragma unroll
+            for (int fb = 0; fb < FB; ++fb) {
+                h16 h, l;
+                split2(v[rr][fb], h, l);
+                X.hi[(size_t)r * X.stride + fb * 16 + sl] = h;
+                X.lo[(size_t)r * X.stride + fb * 16 + sl] = l;
+            }
+        }
+    }
+    for (int r = MAXR * NGR + gq; r < nrow; r += NGR) {            // tiles of more than MAXR * NGR rows (none of the BASELINE shapes)
+#pragma unroll
+        for (int fb = 0; fb < FB; ++fb) {
+            const int f = fb * 16 + sl;
+            h16 h, l;
+            split2((r < rows && f < a.d) ? src[(size_t)r * a.d + f] : 0.0f, h, l);
+            X.hi[(size_t)r * X.stride + f] = h;
+            X.lo[(size_t)r * X.stride + f] = l;
+        }
     }
 }
 
@@ -226,7 +344,7 @@ __device__ __forceinline__ void stage_obs(const FwdArgs &a, const Planes X, int 
 //   R1  planes 128 wide  : enc1 output, then the A tile of the aggregation (f32 [rows][NPA]), then head layer 1 output
 //   EP  planes 64 wide   : E
 //   HP  planes 64 wide   : H_l  (the observation planes overlay HP..T before the encoder has run)
-//   T   288 B per row    : Q planes | H.Wg f32 [rows][SF] | head layer 2 output planes
+//   T   288 B per row    : Q planes | H.Wg f32 [rows][SF] (large teams: H.Wg TRANSPOSED planes [env][64][Kp + 8]) | head layer 2 planes
 //   EF  f32 [rows][SF]   : E in f32 - small-team VALU attention only (0 bytes otherwise)
 //   QF  f32 [rows][SF]   : Q in f32 - small-team VALU attention only
 //   M   f32 [EPB*N][NP]  : scores / attention (0 bytes on the teams-of-4 path)
@@ -239,7 +357,9 @@ __host__ __device__ inline LdsMap lds_map(int rows_cap, int epb, int N, int mode
     o.r1 = take(planes_bytes(rows_cap, 128));
     o.ep = take(planes_bytes(rows_cap, 64));
     o.hp = take(planes_bytes(rows_cap, 64));
-    o.t = take(planes_bytes(rows_cap, 64));
+    const size_t kp = (size_t)((N + 31) & ~31);                  // big path: per-env transposed H.Wg planes [64][Kp + 8]
+    const size_t hwt = mode > 0 ? (size_t)epb * 64 * (kp + SHP) * 2 * sizeof(h16) : 0;
+    o.t = take(planes_bytes(rows_cap, 64) > hwt ? planes_bytes(rows_cap, 64) : hwt);
     o.ef = take(mode == 0 ? (size_t)rows_cap * SF * 4 : 0);
     o.qf = take(mode == 0 ? (size_t)rows_cap * SF * 4 : 0);
     o.m = take(mode < 0 ? 0 : (size_t)epb * N * (N | 1) * 4);
@@ -420,18 +540,26 @@ __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, c
             }
             lds_barrier();
             if (a.stop == 41) return;
-            for (int r0 = 0; r0 < rows; r0 += NG) {   // 16 lanes per matrix row, DPP row reductions
-                const int r = min(r0 + (tid >> 4), rows - 1), sl = tid & 15;
-                float *m = M + (size_t)r * NP;
-                float mx = -INFINITY;
-                for (int j = sl; j < N; j += 16) mx = fmaxf(mx, m[j]);
-                mx = mf::row16_max(mx);
-                float sum = 0.0f;
-                for (int j = sl; j < N; j += 16) { const float ex = __builtin_amdgcn_exp2f((m[j] - mx) * 1.4426950408889634f); sum += ex; if (r0 + (tid >> 4) < rows) m[j] = ex; }
-                sum = mf::row16_sum(sum);
-                const float rsum = __builtin_amdgcn_rcpf(sum);
-                if (r0 + (tid >> 4) < rows)
-                    for (int j = sl; j < N; j += 16) m[j] = m[j] * rsum;
+            {   // softmax: 16 lanes per matrix row, DPP row reductions; the row stays in registers between the passes
+                constexpr int JBS = (MAXMK == 25 || MAXMK == 15) ? 5 : 8;          // column blocks per row (N <= 16 * JBS)
+                for (int r0 = 0; r0 < rows; r0 += NG) {
+                    const int r = min(r0 + (tid >> 4), rows - 1), sl = tid & 15;
+                    float *m = M + (size_t)r * NP;
+                    float x[JBS];
+                    float mx = -INFINITY;
+#pragma unroll
+                    for (int jb = 0; jb < JBS; ++jb) { const int j = jb * 16 + sl; x[jb] = j < N ? m[j] : -INFINITY; mx = fmaxf(mx, x[jb]); }
+                    mx = mf::row16_max(mx);
+                    float sum = 0.0f;
+#pragma unroll
+                    for (int jb = 0; jb < JBS; ++jb) { x[jb] = __builtin_amdgcn_exp2f((x[jb] - mx) * 1.4426950408889634f); sum += x[jb]; }   // exp2(-inf) = 0
+                    sum = mf::row16_sum(sum);
+                    const float rsum = __builtin_amdgcn_rcpf(sum);
+                    if (r0 + (tid >> 4) < rows) {
+#pragma unroll
+                        for (int jb = 0; jb < JBS; ++jb) { const int j = jb * 16 + sl; if (j < N) m[j] = x[jb] * rsum; }
+                    }
+                }
             }
         } else {
             for (int k = tid; k < envs * NN; k += TPBW) {
@@ -457,14 +585,23 @@ __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, c
         }
         lds_barrier();
         if (a.stop == 42) return;
-        if (a.attn) {
-            float *dst = a.attn + (size_t)s0 * NN;
-            if (big) {
-                for (int r = tid >> 4; r < rows; r += NG)
-                    for (int j = tid & 15; j < N; j += 16) dst[(size_t)r * N + j] = M[(size_t)r * NP + j];
-            } else {
-                for (int k = tid; k < envs * NN; k += TPBW) { const int r = k / N, j = k - r * N; dst[k] = M[(size_t)r * NP + j]; }
+        if (big && L > 0) {
+            // k-padding of the aggregation operands, zeroed once (the hops only ever write k < N): the tail [N, Kp) of every
+            // HWt feature row (Q in T is dead: the scores are done) and the A tile's columns the build loop never reaches
+            constexpr int JBZ = (MAXMK == 25 || MAXMK == 15) ? 5 : 8;
+            const int Kp0 = (N + 31) & ~31, ks0 = Kp0 + SHP, pad = Kp0 - N;
+            h16 *zh = reinterpret_cast<h16 *>(lds + lm.t), *zl = zh + (size_t)a.EPB * EMB * ks0;
+            for (int k = tid; k < envs * EMB * pad; k += TPBW) {
+                const int fe = k / pad, j = N + (k - fe * pad);
+                zh[(size_t)fe * ks0 + j] = (h16)0.0f; zl[(size_t)fe * ks0 + j] = (h16)0.0f;
             }
+            const int z0 = JBZ * 16 < Kp0 ? JBZ * 16 : Kp0, zc = Kp0 - z0;
+            const Planes Az = planes_at(lds + lm.r1, rows_cap, Kp0);
+            for (int k = tid; k < rows * zc; k += TPBW) {
+                const int r = k / zc, j = z0 + (k - r * zc);
+                Az.hi[(size_t)r * Az.stride + j] = (h16)0.0f; Az.lo[(size_t)r * Az.stride + j] = (h16)0.0f;
+            }
+            // (ordered before the first use by the barriers inside hop 0: run_hwt / the A-tile build write disjoint addresses)
         }
         if (a.stop == 5) return;
         for (int l = 0; l < L; ++l) {
@@ -488,12 +625,16 @@ __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, c
                     mk[qq] = v;
                 }
             }
-            l_sq.template run<false, OUT_F32>(Hin, Hin, HW, SF, RT, wave, lane);                // H.Wg_l -> f32 in T
+            // large teams: aggregation on the f16 pipe as well - H.Wg_l as transposed planes, the A tile as planes
+            const int Kp = (N + 31) & ~31, KBQ = Kp >> 5, kstride = Kp + SHP;
+            h16 *hwt_hi = reinterpret_cast<h16 *>(lds + lm.t), *hwt_lo = hwt_hi + (size_t)a.EPB * EMB * kstride;
+            const Planes Am = planes_at(lds + lm.r1, rows_cap, Kp);                             // A tile [rows][Kp] over R1
+            if (big) l_sq.run_hwt(Hin, hwt_hi, hwt_lo, kstride, N, rows, envs, RT, wave, lane);  // H.Wg_l -> HWt planes in T
+            else l_sq.template run<false, OUT_F32>(Hin, Hin, HW, SF, RT, wave, lane);           // H.Wg_l -> f32 in T
             if (a.stop == 61 + l) return;
             if (l + 1 < L) l_sq.load(tw.gcn_p + (size_t)(l + 1) * LayerH<EMB, EMB, NW>::PACK_U4, nullptr, wave, lane);
             if (MAXMK > 0 && big) {
-                const int NPA = (((N + 15) >> 4) << 4) + 4;
-                {   // A row = M row * mask, renormalised: 16 lanes per row, DPP row sum, one pass
+                {   // A row = M row * mask, renormalised: 16 lanes per row, DPP row sum, one pass; written as f16 planes
                     const int gq = tid >> 4, sl = tid & 15;
 #pragma unroll
                     for (int rbk = 0; rbk < MAXMK / JB; ++rbk) {
@@ -511,55 +652,60 @@ __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, c
                             }
                             const float rden = __builtin_amdgcn_rcpf(mf::row16_sum(sum) + 1e-12f);
                             if (lv) {
-                                float *ar = Amat + (size_t)r * NPA;
 #pragma unroll
-                                for (int jb = 0; jb < JB; ++jb) { const int j = jb * 16 + sl; if (j < NPA) ar[j] = j < N ? v[jb] * rden : 0.0f; }
+                                for (int jb = 0; jb < JB; ++jb) {
+                                    const int j = jb * 16 + sl;
+                                    if (j < Kp) {
+                                        h16 h, lo_; split2(j < N ? v[jb] * rden : 0.0f, h, lo_);
+                                        Am.hi[(size_t)r * Am.stride + j] = h; Am.lo[(size_t)r * Am.stride + j] = lo_;
+                                    }
+                                }
                             }
                         }
                     }
                 }
                 lds_barrier();
                 if (a.stop == 51 + l) return;
-                {   // aggregation on v_mfma_f32_16x16x4_f32 with swapped operands: D'[feature][row] = sum_k HW[k][feature] A[row][k].
+                {   // D'[feature][row] = sum_k HWt[feature][k] A[row][k]: both operands are 8 consecutive k per lane (b128).
                     // Wave w owns features 16 (w & 3) .. +15; with 8 waves two waves share them and split the row tiles.
-                    constexpr int MAXKS = 32;
-                    const int c = lane & 15, g = lane >> 4, NT = (N + 15) >> 4, KQ = NT;
-                    const int colA = (wave & 3) * 16 + c;                 // feature this lane supplies as the A operand
-                    const int f0 = (wave & 3) * 16 + 4 * g;               // first of the four features this lane ends up with
+                    constexpr int MAXKB = (MAXMK == 25 || MAXMK == 15) ? 3 : 4;        // N <= 80 -> Kp <= 96; N <= 128 -> Kp <= 128
+                    const int c = lane & 15, g = lane >> 4, NT = (N + 15) >> 4;
+                    const int ft = wave & 3, f0 = ft * 16 + 4 * g;
                     const int rt0 = 2 * (wave >> 2), rt_stride = 2 * (NW >> 2);
                     float bvr[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) bvr[r] = tw.gcn_b ? tw.gcn_b[(size_t)l * EMB + f0 + r] : 0.0f;
                     for (int e = 0; e < envs; ++e) {
-                        float b[MAXKS];
+                        v8h ah[MAXKB], al[MAXKB];
+                        const size_t ao = ((size_t)e * EMB + ft * 16 + c) * kstride + 8 * g;
 #pragma unroll
-                        for (int kk = 0; kk < MAXKS; ++kk) {
-                            const int k = 16 * (kk >> 2) + 4 * g + (kk & 3);
-                            b[kk] = (kk < 4 * KQ && k < N) ? HW[(size_t)(e * N + k) * SF + colA] : 0.0f;
+                        for (int q = 0; q < MAXKB; ++q) {
+                            const int qc = q < KBQ ? q : KBQ - 1;                     // branch-free: steps past KBQ are skipped below
+                            ah[q] = *reinterpret_cast<const v8h *>(hwt_hi + ao + 32 * qc);
+                            al[q] = *reinterpret_cast<const v8h *>(hwt_lo + ao + 32 * qc);
                         }
                         for (int rt = rt0; rt < NT; rt += rt_stride) {
                             const bool hasB = rt + 1 < NT;
-                            const int ra = min(rt * 16 + c, N - 1), rb2 = min((hasB ? rt + 1 : rt) * 16 + c, N - 1);
-                            const float4 *pa = reinterpret_cast<const float4 *>(Amat + (size_t)(e * N + ra) * NPA + 4 * g);
-                            const float4 *pb = reinterpret_cast<const float4 *>(Amat + (size_t)(e * N + rb2) * NPA + 4 * g);
-                            float4 xa[MAXKS / 4], xb[MAXKS / 4];
+                            const size_t ra = (size_t)(e * N + min(rt * 16 + c, N - 1)) * Am.stride + 8 * g;
+                            const size_t rb2 = (size_t)(e * N + min((hasB ? rt + 1 : rt) * 16 + c, N - 1)) * Am.stride + 8 * g;
+                            v8h xh0[MAXKB], xl0[MAXKB], xh1[MAXKB], xl1[MAXKB];
 #pragma unroll
-                            for (int kq = 0; kq < MAXKS / 4; ++kq) {
-                                const int kc = kq < KQ ? kq : KQ - 1;
-                                xa[kq] = pa[4 * kc]; xb[kq] = pb[4 * kc];
+                            for (int q = 0; q < MAXKB; ++q) {
+                                const int qc = q < KBQ ? q : KBQ - 1;
+                                xh0[q] = *reinterpret_cast<const v8h *>(Am.hi + ra + 32 * qc); xl0[q] = *reinterpret_cast<const v8h *>(Am.lo + ra + 32 * qc);
+                                xh1[q] = *reinterpret_cast<const v8h *>(Am.hi + rb2 + 32 * qc); xl1[q] = *reinterpret_cast<const v8h *>(Am.lo + rb2 + 32 * qc);
                             }
-                            v4f acc0 = (v4f){ bvr[0], bvr[1], bvr[2], bvr[3] }, acc1 = acc0;
+                            v4f hh0 = (v4f){ bvr[0], bvr[1], bvr[2], bvr[3] }, hh1 = hh0;
+                            v4f ca0 = (v4f){ 0.f, 0.f, 0.f, 0.f }, ca1 = ca0, cb0 = ca0, cb1 = ca0;
 #pragma unroll
-                            for (int kq = 0; kq < MAXKS / 4; ++kq) {
-                                if (kq < KQ) {
-                                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b[4 * kq + 0], xa[kq].x, acc0, 0, 0, 0);
-                                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b[4 * kq + 0], xb[kq].x, acc1, 0, 0, 0);
-                                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b[4 * kq + 1], xa[kq].y, acc0, 0, 0, 0);
-                                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b[4 * kq + 1], xb[kq].y, acc1, 0, 0, 0);
-                                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b[4 * kq + 2], xa[kq].z, acc0, 0, 0, 0);
-                                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b[4 * kq + 2], xb[kq].z, acc1, 0, 0, 0);
-                                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b[4 * kq + 3], xa[kq].w, acc0, 0, 0, 0);
-                                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b[4 * kq + 3], xb[kq].w, acc1, 0, 0, 0);
+                            for (int q = 0; q < MAXKB; ++q) {
+                                if (q < KBQ) {
+                                    hh0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[q], xh0[q], hh0, 0, 0, 0);
+                                    hh1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[q], xh1[q], hh1, 0, 0, 0);
+                                    ca0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[q], xl0[q], ca0, 0, 0, 0);
+                                    ca1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[q], xl1[q], ca1, 0, 0, 0);
+                                    cb0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[q], xh0[q], cb0, 0, 0, 0);
+                                    cb1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[q], xh1[q], cb1, 0, 0, 0);
                                 }
                             }
                             // lane (c, g): features f0 .. f0+3 of rows rt*16 + c and (rt+1)*16 + c
@@ -575,7 +721,8 @@ __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, c
                                     }
 #pragma unroll
                                     for (int r = 0; r < 4; ++r) {
-                                        float hv = fast_tanh(half == 0 ? acc0[r] : acc1[r]);
+                                        const float pre = half == 0 ? fmaf(ca0[r] + cb0[r], LO_INV, hh0[r]) : fmaf(ca1[r] + cb1[r], LO_INV, hh1[r]);
+                                        float hv = fast_tanh(pre);
                                         if (last && !a.no_residual) hv += join2(eh[r], el[r]);
                                         h16 h, lo_; split2(hv, h, lo_); oh[r] = h; ol[r] = lo_;
                                     }
@@ -665,6 +812,19 @@ __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, c
         lds_barrier();
     }
 
+    // attention output of the general path: written LAST.  Vector-memory operations retire in issue order, so these
+    // ~20 KB of stores per env would sit in front of every later mask / weight load if issued right after the softmax;
+    // M is not touched by the hops or the head, so it can leave at the very end and drain while the workgroup retires.
+    auto store_attention = [&]() {
+        if (quad_path || !a.attn) return;
+        float *dst = a.attn + (size_t)s0 * NN;
+        if (big) {
+            for (int r = tid >> 4; r < rows; r += NG)
+                for (int j = tid & 15; j < N; j += 16) dst[(size_t)r * N + j] = M[(size_t)r * NP + j];
+        } else {
+            for (int k = tid; k < envs * NN; k += TPBW) { const int r = k / N, j = k - r * N; dst[k] = M[(size_t)r * NP + j]; }
+        }
+    };
     if (!quad_path) l_x1.load(HEAD == 0 ? ph.h1_p : chd.d1_p, HEAD == 0 ? ph.b1 : chd.b1, wave, lane);
     if (HEAD == 0) {
         if (big) l_h2.load(ph.h2_p, ph.b2, wave, lane);
@@ -727,6 +887,7 @@ __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, c
                 if (act_lds) act_lds[r] = act;
             }
         }
+        store_attention();
     } else {
         float *XF = reinterpret_cast<float *>(lds + lm.r1);                                  // critic: tanh(x1) f32 [rows][SF] in R1
         l_x1.template run<true, OUT_F32>(Hp, Hp, XF, SF, RT, wave, lane);
