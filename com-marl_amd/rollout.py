@@ -45,7 +45,8 @@ class _Parts:
 
 
 class RolloutEngine:
-    def __init__(self, env, policy, horizon, store_attn=True, store_probs=True, fused=True, persistent=False):
+    def __init__(self, env, policy, horizon, store_attn=True, store_probs=True, fused=True, persistent=False,
+                 graph_fused=True):
         """env: envs.GridEnvBatch, or a list of shards of one batch (then every shard runs its own
         policy -> env chain on its own HIP stream: the chains are independent, so kernels of different
         shards overlap and their phases drift apart instead of contending in lockstep).
@@ -89,6 +90,11 @@ class RolloutEngine:
         self._fused = None if fused else False              # None = try the fused step, False = two launches per step
         self._persistent = bool(persistent and fused)
         self._capturing = False
+        # captured chunks: one fused launch per step (cm_rollout_step) or the two-kernel form - measured per config in
+        # bench.py; COMMARL_GRAPH_FUSED=0/1 forces either for A/B runs
+        import os
+        env = os.environ.get("COMMARL_GRAPH_FUSED")
+        self._fused_in_graph = bool(fused) and (env == "1" if env is not None else bool(graph_fused))
         self.t = 0
 
     @property
@@ -128,7 +134,7 @@ class RolloutEngine:
     def _step_part(self, k, t, greedy):
         part, (lo, hi) = self.parts[k], self.bounds[k]
         nb = hi - lo
-        if self._fused is not False and not self._capturing and hasattr(self.policy, "step_fused"):
+        if self._fused is not False and (not self._capturing or self._fused_in_graph) and hasattr(self.policy, "step_fused"):
             # policy forward + sample + env step of this shard in one launch (cm_rollout_step); shapes without a fused
             # kernel report "not available" once and the two-launch path below is used from then on
             ok = self.policy.step_fused(
@@ -184,17 +190,14 @@ class RolloutEngine:
         if self.channels is not None:
             self.channels[0][lo:hi].copy_(self.channels[n][lo:hi])
 
-    def _chunk_part(self, k, n):
-        """Shard k: n steps from slot 0, then its counter bump and its slot-n -> slot-0 carry, all on the current
-        stream (the shard's own): one branch of the captured chunk graph."""
-        for t in range(n):
-            self._step_part(k, t, False)
+    def _chunk_tail(self, k, n):
+        """Shard k: counter bump + slot n -> slot 0 in one launch (cm_chunk_tail) on the current stream."""
         lo, hi = self.bounds[k]
         pairs = [(b[n][lo:hi], b[0][lo:hi]) for b in (self.obs, self.dist_adj, self.channels) if b is not None]
         args = []
         for src, dst in pairs + [(None, None)] * (3 - len(pairs)):
             args += [L.ptr(src), L.ptr(dst), 0 if src is None else src.numel() * src.element_size()]
-        with torch.cuda.device(self.env.device):            # counter bump + slot n -> slot 0 in one launch
+        with torch.cuda.device(self.env.device):
             L.check(L.lib().cm_chunk_tail(L.ptr(self.step_bases[k]), n, *args, L.current_stream()), "cm_chunk_tail")
 
     def _strides(self):
@@ -233,11 +236,18 @@ class RolloutEngine:
         return True
 
     def _chunk(self, n):
-        """All shards: fork, every shard's n-step chain (+ its tail) on its own stream, join."""
+        """All shards: fork, every shard's n-step chain (+ its tail) on its own stream, join.  The launches are issued
+        step by step across the shards (t outer, shard inner): a captured graph submits its nodes in capture order, so
+        issuing one shard's whole chain first would start the other shard's chain only after it (measured: ~100 us
+        stagger per replay, profiles/r02_trace_short.txt)."""
         self.fork()
+        for t in range(n):
+            for k, st in enumerate(self.streams):
+                with torch.cuda.stream(st) if st is not None else _null():
+                    self._step_part(k, t, False)
         for k, st in enumerate(self.streams):
             with torch.cuda.stream(st) if st is not None else _null():
-                self._chunk_part(k, n)
+                self._chunk_tail(k, n)
         self.join()
 
     def prepare_graph(self, n=None):
