@@ -116,6 +116,10 @@ _SIGNATURES = {
                                   C.c_void_p]),
     "cm_chunk_tail": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                 C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "cm_linear_act_forward": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                        C.c_int32, C.c_void_p, C.c_void_p]),
+    "cm_linear_act_backward": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cm_discount_returns": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p,
                                       C.c_void_p]),
     "cm_gae": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int32,

@@ -14,6 +14,7 @@ garage/torch/modules/multi_headed_mlp_module.py.
 """
 import ctypes as C
 import math
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -57,8 +58,9 @@ class MLPModule(nn.Module):
 
     def forward(self, x):
         for layer in self._layers:
-            x = layer(x)
-        return self._output_layers[0](x)
+            x = hip_linear(x, layer.linear, act=1)                       # Sequential(linear, tanh) as one fused op
+        out = self._output_layers[0]
+        return hip_linear(x, out.linear, act=1 if len(out) > 1 else 0)
 
 
 class _AttentionSoftmax(torch.autograd.Function):
@@ -167,11 +169,56 @@ class _MatmulWFn(torch.autograd.Function):
         return dh, dw
 
 
-def hip_linear(x, lin):
-    """nn.Linear forward; on the GPU with autograd on, the backward uses the custom weight-gradient kernel."""
+class _LinearActFn(torch.autograd.Function):
+    """y = act(x W^T + b) (layout 0, nn.Linear) or act(x W) (layout 1, GraphConvolution weight) as ONE kernel each way
+    (csrc/cm_linear.hip): forward reads x and writes y; backward reads dy, y, x and writes dx while the weight and
+    bias gradients accumulate in registers - instead of torch's GEMM, tanh, tanh', input-gradient GEMM and
+    weight-gradient GEMM, each a full HBM pass over the [rows, 64..128] activations of ~1e6 agent rows."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act, layout):
+        K = x.shape[-1]
+        O = weight.shape[0] if layout == 0 else weight.shape[1]
+        x2 = x.reshape(-1, K).contiguous()
+        w = weight.contiguous()
+        y = torch.empty(x2.shape[0], O, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            L.check(L.lib().cm_linear_act_forward(x2.shape[0], K, O, L.ptr(x2), L.ptr(w), layout,
+                                                  L.ptr(None if bias is None else bias.contiguous()), int(act), L.ptr(y),
+                                                  L.current_stream()), "cm_linear_act_forward")
+        ctx.save_for_backward(x2, w, y if act else None)
+        ctx.meta = (tuple(x.shape), K, O, int(act), layout, bias is not None)
+        return y.reshape(*x.shape[:-1], O)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, y = ctx.saved_tensors
+        shape, K, O, act, layout, has_bias = ctx.meta
+        dy2 = dy.reshape(-1, O).contiguous()
+        dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        dw = torch.zeros_like(w)
+        db = torch.zeros(O, dtype=torch.float32, device=w.device) if has_bias else None
+        with torch.cuda.device(w.device):
+            L.check(L.lib().cm_linear_act_backward(x2.shape[0], K, O, L.ptr(x2), L.ptr(w), layout, L.ptr(dy2), L.ptr(y),
+                                                   L.ptr(dx), L.ptr(dw), L.ptr(db), L.current_stream()),
+                    "cm_linear_act_backward")
+        return (None if dx is None else dx.reshape(shape)), dw, db, None, None
+
+
+def _fused_ok(x, weight):
+    return (x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and weight.requires_grad
+            and max(weight.shape) <= 128 and os.environ.get("COMMARL_FUSED_LINEAR", "1") != "0")
+
+
+def hip_linear(x, lin, act=0):
+    """nn.Linear (+ tanh when act) forward; on the GPU with autograd on it is the fused one-pass kernel pair."""
+    if _fused_ok(x, lin.weight):
+        return _LinearActFn.apply(x, lin.weight, lin.bias, act, 0)
     if x.is_cuda and torch.is_grad_enabled() and lin.weight.requires_grad and max(lin.weight.shape) <= 128:
-        return _LinearFn.apply(x, lin.weight, lin.bias)
-    return torch.nn.functional.linear(x, lin.weight, lin.bias)
+        y = _LinearFn.apply(x, lin.weight, lin.bias)
+    else:
+        y = torch.nn.functional.linear(x, lin.weight, lin.bias)
+    return torch.tanh(y) if act else y
 
 
 class HipLinear(nn.Linear):
@@ -337,7 +384,10 @@ class CommBaseNet(_WeightPack, nn.Module):
         M = self.attention_layer(E)
         H = E
         for l, g in enumerate(self.gcn_layers):
-            hw = _MatmulWFn.apply(H, g.weight) if (H.is_cuda and torch.is_grad_enabled()) else torch.matmul(H, g.weight)
+            if _fused_ok(H, g.weight):
+                hw = _LinearActFn.apply(H, g.weight, None, 0, 1)        # H.Wg, weight [in,out]
+            else:
+                hw = _MatmulWFn.apply(H, g.weight) if (H.is_cuda and torch.is_grad_enabled()) else torch.matmul(H, g.weight)
             H = masked_aggregate(M, adj, ch, l, hw, g.bias)
         return E, H, M
 

@@ -291,6 +291,19 @@ int cm_attention_backward(int32_t S, int32_t N, int32_t E, const float *q, const
 int cm_linear_wgrad(int64_t R, int32_t P, int32_t Q, const float *a, const float *b, float *c, float *colsum_a,
                     void *stream);
 
+/* One dense per-agent layer of the PPO update, one HBM pass each way (csrc/cm_linear.hip).
+ * w_layout 0: w is nn.Linear's [out,in] (multi_headed_mlp_module.py:134-149, attention_module.py:36);
+ * w_layout 1: w is GraphConvolutionModule's [in,out] (graph_conv_module.py:63).  1 <= in, out <= 128.
+ *   forward :  y[r][o] = act(bias[o] + sum_k x[r][k] w(k,o)),  act 0 = identity, 1 = tanh; bias may be NULL.
+ *   backward:  dz = dy * (1 - y^2) when y != NULL (tanh layer), dz = dy when y == NULL;
+ *              dx[r][k] = sum_o dz[r][o] w(k,o)   (dx may be NULL: first layer);
+ *              dw += dz^T.x in w's own layout and db += colsum(dz) (db may be NULL), float atomics:
+ *              the caller zeroes dw / db. */
+int cm_linear_act_forward(int64_t R, int32_t in_dim, int32_t out_dim, const float *x, const float *w, int32_t w_layout,
+                          const float *bias, int32_t act, float *y, void *stream);
+int cm_linear_act_backward(int64_t R, int32_t in_dim, int32_t out_dim, const float *x, const float *w, int32_t w_layout,
+                           const float *dy, const float *y, float *dx, float *dw, float *db, void *stream);
+
 /* tensor_utils.discount_cumsum (garage/misc/tensor_utils.py:7-23) per path over a padded
  * [P,T] batch: f64 recurrence, f32 result, zero past lens[p]. */
 int cm_discount_returns(int32_t P, int32_t T, const double *rewards, const int32_t *lens, double gamma,

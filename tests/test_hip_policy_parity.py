@@ -230,6 +230,46 @@ def test_linear_weight_gradient_kernel(R, IN, OUT, torch_cuda):
         np.testing.assert_allclose(w.grad.cpu().numpy(), w2.grad.cpu().numpy(), rtol=2e-4, atol=2e-5 * float(w2.grad.abs().max()))
 
 
+@pytest.mark.parametrize("R,IN,OUT,act,layout", [(1000, 21, 128, 1, 0), (70001, 128, 64, 1, 0), (4097, 64, 64, 0, 1),
+                                                  (333, 64, 128, 1, 0), (5000, 32, 5, 0, 0), (129, 64, 1, 0, 0),
+                                                  (64, 77, 128, 1, 0), (100000, 128, 128, 1, 0), (63, 64, 64, 0, 0),
+                                                  (300001, 64, 32, 1, 0)])
+def test_fused_linear_act_kernels(R, IN, OUT, act, layout, torch_cuda):
+    """cm_linear_act_forward / backward (one HBM pass each: y = act(x W^T + b); dx, dW, db from dy, y, x) against an f64
+    torch reference of the same layer - forward and every gradient, both weight layouts, ragged last chunks.
+    Tolerances: forward 1e-5; gradients relative to the largest entry of the f64 result (sums over up to 3e5 rows of
+    f32 products, merged across workgroups with float atomics: order-dependent in the last bits)."""
+    torch = torch_cuda
+    from com_marl_amd.nets import _LinearActFn
+    g = torch.Generator().manual_seed(R + IN + OUT)
+    x = torch.randn(R, IN, generator=g).cuda()
+    dy = torch.randn(R, OUT, generator=g).cuda()
+    w = (torch.randn(OUT, IN, generator=g) * 0.2).cuda() if layout == 0 else (torch.randn(IN, OUT, generator=g) * 0.2).cuda()
+    b = (torch.randn(OUT, generator=g) * 0.1).cuda() if layout == 0 else None
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    br = None if b is None else b.clone().requires_grad_()
+    y = _LinearActFn.apply(xr, wr, br, act, layout)
+    y.backward(dy)
+    x6, w6 = x.double().requires_grad_(), w.double().requires_grad_()
+    b6 = None if b is None else b.double().requires_grad_()
+    z = x6 @ (w6.t() if layout == 0 else w6)
+    if b6 is not None:
+        z = z + b6
+    y6 = torch.tanh(z) if act else z
+    y6.backward(dy.double())
+    np.testing.assert_allclose(y.detach().cpu().numpy(), y6.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(xr.grad.cpu().numpy(), x6.grad.cpu().numpy(), rtol=1e-5, atol=2e-5)
+    for got, want in ((wr.grad, w6.grad), (None if br is None else br.grad, None if b6 is None else b6.grad)):
+        if want is None:
+            continue
+        scale = float(want.abs().max())
+        np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=2e-6 * scale)
+    # first layer form: no input gradient requested
+    wr2 = w.clone().requires_grad_()
+    _LinearActFn.apply(x, wr2, None if b is None else b, act, layout).backward(dy)
+    np.testing.assert_allclose(wr2.grad.cpu().numpy(), w6.grad.cpu().numpy(), rtol=1e-5, atol=2e-6 * float(w6.grad.abs().max()))
+
+
 @pytest.mark.parametrize("d,n_agents,residual,hops", [(21, 4, False, 2), (100, 4, True, 2), (100, 6, False, 1), (29, 3, True, 3),
                                                       (77, 24, False, 2), (53, 72, True, 1), (21, 8, True, 2), (29, 16, True, 2),
                                                       (53, 20, False, 2), (77, 32, True, 2), (12, 36, True, 2), (40, 80, False, 3),
