@@ -26,13 +26,13 @@ if ROOT not in sys.path:
 CONFIGS = {
     # BASELINE.json configs[1] - the configuration the metric is quoted on
     "pp_map10": dict(scenario="pp", map=10, sen=1, n_agents=4, n_preys=4, load=2, max_env_steps=200, loss=0.0,
-                     envs=4096, step_us=36, label="PredatorPrey map=10 sen=1 den=0.04 cap=2 (N=M=4), Comm-DP GNN policy"),
+                     envs=4096, step_us=30, label="PredatorPrey map=10 sen=1 den=0.04 cap=2 (N=M=4), Comm-DP GNN policy"),
     "co_map20": dict(scenario="co", map=20, sen=2, n_agents=24, n_preys=0, load=2, max_env_steps=400, loss=0.0,
-                     envs=2048, step_us=129, label="Coverage map=20 sen=2 den=0.06 (N=24), Comm-DP GNN policy"),
+                     envs=2048, step_us=100, label="Coverage map=20 sen=2 den=0.06 (N=24), Comm-DP GNN policy"),
     "pp_map30": dict(scenario="pp", map=30, sen=2, n_agents=72, n_preys=72, load=4, max_env_steps=200, loss=0.0,
-                     envs=1024, step_us=250, label="PredatorPrey map=30 sen=2 den=0.08 cap=4 (N=M=72), Comm-DP GNN policy"),
+                     envs=1024, step_us=180, streams=1, label="PredatorPrey map=30 sen=2 den=0.08 cap=4 (N=M=72), Comm-DP GNN policy"),
     "co_map30": dict(scenario="co", map=30, sen=2, n_agents=54, n_preys=0, load=2, max_env_steps=400, loss=0.3,
-                     envs=1024, step_us=203, label="Coverage map=30 sen=2 den=0.06 loss=0.3 IID (N=54), Comm-DP GNN policy"),
+                     envs=1024, step_us=150, label="Coverage map=30 sen=2 den=0.06 loss=0.3 IID (N=54), Comm-DP GNN policy"),
 }
 
 
@@ -304,11 +304,24 @@ def main():
         return ev0.elapsed_time(ev1) / (reps * inner) * 1e-3                 # seconds per launch
 
     env.reset_all()                                     # full-batch handle: per-launch kernel times at B envs
+    adj0 = None if eng.dist_adj is None else eng.dist_adj[0]
+    ch0 = None if eng.channels is None else eng.channels[0]
     t_pol = time_kernel(lambda: policy.act_device(
-        eng.obs[0].view(B, -1), None, None if eng.dist_adj is None else eng.dist_adj[0],
-        None if eng.channels is None else eng.channels[0], out_actions=eng.actions[0], out_probs=eng.probs[0],
+        eng.obs[0].view(B, -1), None, adj0, ch0, out_actions=eng.actions[0], out_probs=eng.probs[0],
         out_attn=None if eng.attn is None else eng.attn[0], policy_step=0, step_base=eng.step_base))
     t_env = time_kernel(lambda: env.step_device(eng.actions[0], out=eng._out(0, 0, B)))
+    # the timed region's own launch: policy forward + sample + env step of the whole batch in ONE kernel (cm_rollout_step);
+    # None where the library has no fused instantiation for the shape (Obs-DP / CENT policies, unusual obs dims)
+    t_fused = None
+    if eng._fused_in_graph and hasattr(policy, "step_fused"):
+        so = env._out(eng._out(0, 0, B))
+        if policy.step_fused(env, eng.obs[0].view(B, -1), adj0, ch0, so, out_actions=eng.actions[0], out_probs=eng.probs[0],
+                             out_attn=None if eng.attn is None else eng.attn[0], policy_step=0, step_base=eng.step_base,
+                             env_id_offset=rank * B):
+            t_fused = time_kernel(lambda: policy.step_fused(
+                env, eng.obs[0].view(B, -1), adj0, ch0, so, out_actions=eng.actions[0], out_probs=eng.probs[0],
+                out_attn=None if eng.attn is None else eng.attn[0], policy_step=0, step_base=eng.step_base,
+                env_id_offset=rank * B))
     env.check_status()
     b_env, b_pol = algorithmic_bytes(c, env.d, env.adj_const, env.ch_const)
     flops = (policy_flops(c, env.d) if args.policy == "commdp" else variant_flops(c, env.d, args.policy)) * B
@@ -322,16 +335,28 @@ def main():
             traffic = json.load(open(tpath)).get(args.config)
         except Exception:
             traffic = None
-    kernels = {
-        kname: dict(bound="mfma", achieved=flops / t_pol / 1e12, peak=157.3, unit="TFLOP/s",
-                                  frac=flops / t_pol / 1e12 / 157.3, us=t_pol * 1e6,
-                                  hbm_GBps=b_pol * B / t_pol / 1e9),
-        "cm_env_step": dict(bound="hbm", achieved=b_env * B / t_env / 1e9, peak=8000.0, unit="GB/s",
-                            frac=b_env * B / t_env / 1e9 / 8000.0, us=t_env * 1e6),
-    }
-    dom = kname if t_pol >= t_env else "cm_env_step"
-    roofline = dict(kernel=dom, **{k: kernels[dom][k] for k in ("bound", "achieved", "peak", "unit", "frac")},
+
+    def kernel_row(bound, t, fl, nbytes):
+        """`bound` names the roofline the kernel is priced on (SURVEY.md §8d names HBM for the path; the policy forward's
+        arithmetic intensity - ~700 FLOP/B - puts it under the f32 matrix roof instead); both fractions
+        are always emitted: frac against `bound`, hbm_frac = algorithmic bytes / time against 8 TB/s."""
+        tf, gbs = fl / t / 1e12, nbytes / t / 1e9
+        row = dict(bound=bound, us=t * 1e6, hbm_GBps=gbs, hbm_frac=gbs / 8000.0, algorithmic_bytes=nbytes)
+        if bound == "mfma":
+            row.update(achieved=tf, peak=157.3, unit="TFLOP/s", frac=tf / 157.3, flops=fl)
+        else:
+            row.update(achieved=gbs, peak=8000.0, unit="GB/s", frac=gbs / 8000.0)
+        return row
+    kernels = {kname: kernel_row("mfma", t_pol, flops, b_pol * B), "cm_env_step": kernel_row("hbm", t_env, 0, b_env * B)}
+    if t_fused is not None:
+        kernels["cm_rollout_step"] = kernel_row("mfma", t_fused, flops, (b_env + b_pol) * B)
+    # the dominant kernel of the TIMED REGION: the fused rollout step when the chunks were captured with it
+    dom = "cm_rollout_step" if t_fused is not None else (kname if t_pol >= t_env else "cm_env_step")
+    roofline = dict(kernel=dom, **{k: kernels[dom][k] for k in ("bound", "achieved", "peak", "unit", "frac", "hbm_frac")},
                     traffic=(traffic or {}).get(dom) if isinstance(traffic, dict) else None,
+                    note=("peak = dense f32 MFMA (the arithmetic is f32-grade: each 16x16x32 block runs as three "
+                          "v_mfma_f32_16x16x32_f16 on (hi, lo) operand pairs, DESIGN.md §4); achieved = algorithmic FLOPs / "
+                          "HIP-event time of graph-replayed back-to-back launches of the whole per-GPU batch"),
                     kernels=kernels,
                     hot_path=dict(bound="hbm", achieved=(b_env + b_pol) * B * args.steps / dt / 1e9 / world, peak=8000.0,
                                   unit="GB/s", frac=(b_env + b_pol) * B * args.steps / dt / 1e9 / world / 8000.0,
@@ -351,6 +376,8 @@ def main():
                                + "; one step = fused policy forward + sample + env step with auto-reset, "
                                "trajectory written to HBM", "envs_per_gpu": B, "total_envs": B * world, "n_agents": c["n_agents"],
                    "obs_dim": env.d, "graph_chunk": 0 if args.no_graph else G, "streams": ns,
+                   "step_launches": ("1 (cm_rollout_step: policy forward + sample + env step fused)" if eng._fused_in_graph
+                                     and eng._fused else "2 (cm_policy_forward, cm_env_step)"),
                    "graphs": {"count": n_captured, "chunk_lengths": timed_lengths if use_graph else [],
                               "capture_in_timed_region": False,
                               "warmup_steps_run": args.warmup + sum(extra_warm)},

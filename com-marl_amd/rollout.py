@@ -45,7 +45,7 @@ class _Parts:
 
 
 class RolloutEngine:
-    def __init__(self, env, policy, horizon, store_attn=True, store_probs=True, fused=True, persistent=False,
+    def __init__(self, env, policy, horizon, store_attn=True, store_probs=True, fused="auto", persistent=False,
                  graph_fused=True):
         """env: envs.GridEnvBatch, or a list of shards of one batch (then every shard runs its own
         policy -> env chain on its own HIP stream: the chains are independent, so kernels of different
@@ -87,6 +87,12 @@ class RolloutEngine:
         # shard fill the tail of the other's policy kernel).  persistent: run_chunk as ONE cm_rollout_chunk launch per
         # shard - bit-identical, but measured slower on MI355X (the drifting workgroups thrash the instruction cache:
         # 52 us vs 36 us per step at the headline config), so it is opt-in.
+        # fused="auto": the one-launch step only for teams of 4, where it wins (config 2: 27.1 vs 28.5 us per step);
+        # for larger teams the fused kernel runs the env step of ONE env on a 256-thread workgroup that is mostly idle
+        # (measured per step: N = 24 127 vs 95 us, N = 72 424 vs 176 us), so they take the two-kernel form.  True forces
+        # it (parity tests), False disables it.
+        if fused == "auto":
+            fused = getattr(policy, "_n_agents", 0) == 4
         self._fused = None if fused else False              # None = try the fused step, False = two launches per step
         self._persistent = bool(persistent and fused)
         self._capturing = False

@@ -119,7 +119,7 @@ def test_fused_entry_point_reports_unavailable_and_errors():
     spec = E.EnvSpec(E._Box(np.zeros(env.d * 3), np.ones(env.d * 3)), E._Discrete(5))
     pol = nets.CommCategoricalMLPPolicy(spec, n_agents=3, device="cuda:0")
     from com_marl_amd.rollout import RolloutEngine
-    eng = RolloutEngine(env, pol, 4)
+    eng = RolloutEngine(env, pol, 4, fused=True)
     eng.reset()
     for t in range(4):
         eng.step(t)

@@ -70,7 +70,7 @@ def test_rollout_at_baseline_batch_matches_oracle(name, torch_cuda):
     env, pol, crit, oenv = _setup(torch, name)
     B, N = env.B, env.N
     steps = 8
-    eng = RolloutEngine(env, pol, steps)
+    eng = RolloutEngine(env, pol, steps, fused=True)      # force the one-launch step for every shape (auto = teams of 4)
     eng.reset()
     for t in range(steps - 1):
         eng.step(t)
