@@ -114,6 +114,10 @@ _SIGNATURES = {
                                         C.c_void_p, C.c_void_p, C.c_void_p]),
     "cm_linear_wgrad": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p]),
+    "cm_env_agent_condition": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cm_env_agent_fault": (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "cm_comm_delays": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                 C.c_void_p, C.c_void_p]),
     "cm_chunk_tail": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                 C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "cm_linear_act_forward": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,

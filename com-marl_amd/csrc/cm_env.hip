@@ -182,7 +182,7 @@ extern "C" int cm_env_create(const cm_env_cfg *cfg, cm_env_t *out) {
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~size_t(255); return o; };
     const size_t o_ap = take(B * N * sizeof(int2)), o_pp = take(B * (M ? M : 1) * sizeof(int2)), o_al = take(B * (M ? M : 1)),
                  o_vis = take(B * S * 4), o_sc = take(B * 4), o_tc = take(B * 4), o_su = take(B * 4),
-                 o_ge = take(c.channel == CM_CH_GE ? B * N * N : 1), o_rs = take(B * 4), o_st = take(4),
+                 o_ge = take(c.channel == CM_CH_GE ? B * N * N : 1), o_rs = take(B * 4), o_ac = take(B * N), o_st = take(4),
                  o_bg = take((size_t)S * S), o_lr = take(S * 4), o_lc = take(S * 4), o_ls = take((c.max_steps + 1) * 4),
                  o_rl = take(rew_lut.size() * 8);
     h->arena_bytes = off;
@@ -194,6 +194,7 @@ extern "C" int cm_env_create(const cm_env_cfg *cfg, cm_env_t *out) {
     d.agent_pos = (int2 *)(base + o_ap); d.prey_pos = (int2 *)(base + o_pp); d.alive = (uint8_t *)(base + o_al);
     d.visited = (uint32_t *)(base + o_vis); d.step_count = (int32_t *)(base + o_sc); d.total_capture = (int32_t *)(base + o_tc);
     d.success = (int32_t *)(base + o_su); d.ge_state = (uint8_t *)(base + o_ge); d.rng_step = (uint32_t *)(base + o_rs);
+    d.agent_cond = (uint8_t *)(base + o_ac);
     d.status = (int32_t *)(base + o_st);
     d.base_grid = (const uint8_t *)(base + o_bg); d.lut_row = (const float *)(base + o_lr); d.lut_col = (const float *)(base + o_lc);
     d.lut_step = (const float *)(base + o_ls);
@@ -211,6 +212,8 @@ extern "C" int cm_env_create(const cm_env_cfg *cfg, cm_env_t *out) {
             e = hipMemset(base + o_ge, 1, B * N * N);
             if (e != hipSuccess) { hipFree(h->arena); delete h; return hip_fail(e, "hipMemset(GE state)"); }
         }
+        e = hipMemset(base + o_ac, 1, B * N);                            // agent_condition = ones (predator_prey.py:74)
+        if (e != hipSuccess) { hipFree(h->arena); delete h; return hip_fail(e, "hipMemset(agent condition)"); }
     }
     d.lds_env = lds_env_bytes(S, c.n_agents, M ? M : 1);
     {   // lanes per env: the smallest sub-wave group that still gives every agent / prey its own lane
@@ -338,3 +341,82 @@ static int copy_state(cm_env_t h, const cm_env_state *s, bool to_host) {
 
 extern "C" int cm_env_get_state(cm_env_t h, const cm_env_state *host) { return copy_state(h, host, true); }
 extern "C" int cm_env_set_state(cm_env_t h, const cm_env_state *host) { return copy_state(h, host, false); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// dormant fault / delay helpers of custom_implement/env_communication.py:270-301
+// ---------------------------------------------------------------------------------------------------------------
+namespace cm {
+
+// mode 1: iid_fault (:290-292)   cond[i] = 0 iff u_i < p                      (one uniform per agent)
+// mode 2: GE_fault  (:294-301)   AS WRITTEN: np.where's tuple has length 1, so ONE draw decides all good agents
+//                                (stay good iff u_G < 1 - p) and ONE all bad ones (recover iff u_B < r)
+__global__ void agent_fault_kernel(EnvDev d, int mode, float p, float r, const float *__restrict__ tape_u, uint32_t fault_step) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= d.B) return;
+    uint8_t *cond = d.agent_cond + (size_t)b * d.N;
+    const uint32_t env = (uint32_t)(d.env_id_offset + b);
+    if (mode == 1) {
+        for (int i = 0; i < d.N; ++i) {
+            const float u = tape_u ? tape_u[(size_t)b * d.N + i]
+                                   : unit_f32(pick(philox4x32_10(env, fault_step, SITE_FAULT, (uint32_t)(i >> 2), d.key0, d.key1), i & 3));
+            cond[i] = u < p ? 0 : 1;
+        }
+    } else {
+        float ug, ub;
+        if (tape_u) { ug = tape_u[2 * b]; ub = tape_u[2 * b + 1]; }
+        else { const u32x4 x = philox4x32_10(env, fault_step, SITE_FAULT, 0u, d.key0, d.key1); ug = unit_f32(x.x); ub = unit_f32(x.y); }
+        const uint8_t g = ug < 1.0f - p ? 1 : 0, bd = ub < r ? 1 : 0;
+        for (int i = 0; i < d.N; ++i) cond[i] = cond[i] ? g : bd;
+    }
+}
+
+// delays_init (:271-279, init = 1: hop 0 from the adjacency alone, later hops from the link masks alone) and calc_delays
+// (:281-286, init = 0: loss = adjacency * link for every hop, hop 0 counts on from old_delays [B,N,N])
+__global__ void delays_kernel(int B, int L, int N, const float *__restrict__ adj, const float *__restrict__ link,
+                              const int32_t *__restrict__ old_delays, int delay_th, int init, int32_t *__restrict__ delays) {
+    const size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x, NN = (size_t)N * N;
+    if (k >= (size_t)B * NN) return;
+    const size_t b = k / NN, ij = k - b * NN;
+    const float a = adj ? adj[k] : 1.0f;
+    int prev = 0;
+    for (int l = 0; l < L; ++l) {
+        const float lk = link ? link[(b * L + l) * NN + ij] : 1.0f;
+        int v;
+        if (init) v = l == 0 ? (a == 0.0f ? delay_th : 1) : (lk == 0.0f ? prev + 1 : 1);
+        else v = (a * lk == 0.0f) ? (l == 0 ? old_delays[k] : prev) + 1 : 1;
+        delays[(b * L + l) * NN + ij] = v;
+        prev = v;
+    }
+}
+
+}  // namespace cm
+
+extern "C" int cm_env_agent_condition(cm_env_t h, const uint8_t *set_host, uint8_t *get_host) {
+    if (!h) return set_error(CM_ERR_ARG, "null handle");
+    CM_HIP(hipDeviceSynchronize());
+    const size_t n = (size_t)h->dev.B * h->dev.N;
+    if (set_host) CM_HIP(hipMemcpy(h->dev.agent_cond, set_host, n, hipMemcpyHostToDevice));
+    if (get_host) CM_HIP(hipMemcpy(get_host, h->dev.agent_cond, n, hipMemcpyDeviceToHost));
+    return CM_OK;
+}
+
+extern "C" int cm_env_agent_fault(cm_env_t h, int32_t mode, float p, float r, const float *tape_u, uint32_t fault_step, void *stream) {
+    if (!h) return set_error(CM_ERR_ARG, "null handle");
+    if (mode != 1 && mode != 2) return set_error(CM_ERR_ARG, "cm_env_agent_fault: mode 1 (iid_fault) or 2 (GE_fault)");
+    if (h->cfg.rng_mode == CM_RNG_TAPE && !tape_u) return set_error(CM_ERR_ARG, "cm_env_agent_fault: rng_mode is TAPE but no uniforms were passed");
+    hipLaunchKernelGGL(agent_fault_kernel, dim3((h->dev.B + 63) / 64), dim3(64), 0, (hipStream_t)stream, h->dev, mode, p, r, tape_u, fault_step);
+    CM_HIP(hipGetLastError());
+    return CM_OK;
+}
+
+extern "C" int cm_comm_delays(int32_t B, int32_t L, int32_t N, const float *dist_adj, const float *link_loss, const int32_t *old_delays,
+                              int32_t delay_th, int32_t init, int32_t *delays, void *stream) {
+    if (!delays) return set_error(CM_ERR_ARG, "cm_comm_delays: null output");
+    if (!init && !old_delays) return set_error(CM_ERR_ARG, "cm_comm_delays: calc_delays needs old_delays");
+    if (B <= 0 || L <= 0 || N <= 0) return CM_OK;
+    const size_t n = (size_t)B * N * N;
+    hipLaunchKernelGGL(delays_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, B, L, N, dist_adj, link_loss,
+                       old_delays, delay_th, init, delays);
+    CM_HIP(hipGetLastError());
+    return CM_OK;
+}

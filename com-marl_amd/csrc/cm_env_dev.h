@@ -202,6 +202,7 @@ __device__ __forceinline__ void do_reset(const EnvDev &p, const Lds l, const Rng
     }
     if (fail && sl == 0) raise(p, CM_ERR_TAPE);
     if (need) for (int j = sl; j < M; j += LPE) ALV(l, j) = 1;
+    if (need && SCEN == CM_PP) for (int i = sl; i < N; i += LPE) p.agent_cond[(size_t)b * N + i] = 1;   // __init_full_obs :152
     ENV_SYNC();
 }
 
@@ -497,7 +498,11 @@ __device__ __forceinline__ void env_body(const EnvDev &p, const int32_t *__restr
         const int a = act_lds ? act_lds[i] : actions[(size_t)b * N + i];
         const bool bad = (unsigned)a > 4u;
         bad_action |= bad;
-        ACT(l, i) = (uint8_t)(bad ? 4 : a);
+        // agent_condition gate (predator_prey.py:257-261): a faulty agent's move is computed but not applied - it counts
+        // as a moving agent and stays put.  Encoded as the pseudo-action 5 (no displacement): its "target" is its own
+        // occupied cell, which every move resolver below rejects.
+        const bool faulty = SCEN == CM_PP && p.agent_cond[(size_t)b * N + i] == 0;
+        ACT(l, i) = (uint8_t)(bad ? 4 : ((faulty && a != 4) ? 5 : a));
     }
     if (SCEN == CM_PP)
         for (int j = sl; j < M; j += LPE) {

@@ -39,6 +39,7 @@ struct EnvDev {
     int32_t *success;         // [B]
     uint8_t *ge_state;        // [B,N,N]
     uint32_t *rng_step;       // [B]
+    uint8_t *agent_cond;      // [B,N] PP agent_condition (predator_prey.py:74,152,258): 0 = the agent cannot move
     int32_t *status;          // [1] first kernel-side error
     // read-only tables
     const uint8_t *base_grid; // [S*S] CO walls (0 empty / 3 wall)

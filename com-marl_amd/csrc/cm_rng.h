@@ -6,6 +6,7 @@
 //   site 3/4 IID uniforms   (step / reset comm update; idx = flat/4, component flat%4)
 //   site 5/6 GE uniforms    (step / reset; flat = (2*hop + which)*N*N + link)
 //   site 7 action sample    (rng_step := policy_step, idx = agent, x0)
+//   site 9 agent faults     (rng_step := fault_step; iid: idx = agent/4, component agent%4; GE: idx 0, x0 good / x1 bad)
 // Nothing is stored: any draw can be recomputed from (seed, env, step), which is what makes
 // the rollout reproducible across GPU counts (env ids are global).
 #pragma once
@@ -15,7 +16,7 @@
 namespace cm {
 
 enum : uint32_t { SITE_SPAWN = 1, SITE_PREY = 2, SITE_IID_STEP = 3, SITE_IID_RESET = 4, SITE_GE_STEP = 5,
-                  SITE_GE_RESET = 6, SITE_ACTION = 7, SITE_GE_INIT = 8 };
+                  SITE_GE_RESET = 6, SITE_ACTION = 7, SITE_GE_INIT = 8, SITE_FAULT = 9 };
 
 struct u32x4 { uint32_t x, y, z, w; };
 

@@ -197,7 +197,49 @@ class GridEnvBatch:
             L.check(L.lib().cm_env_get_state(self._h, C.byref(cs)), "cm_env_get_state")
         return st
 
+    # ---- dormant fault / delay helpers of the reference (custom_implement/env_communication.py:270-301, SURVEY §8f-3) ----
+    @property
+    def agent_condition(self):
+        """[B,N] uint8: PP agent_condition (predator_prey.py:258): 0 = the agent's moves are not applied."""
+        out = np.zeros((self.B, self.N), np.uint8)
+        with torch.cuda.device(self.device):
+            L.check(L.lib().cm_env_agent_condition(self._h, None, out.ctypes.data), "cm_env_agent_condition")
+        return out
+
+    @agent_condition.setter
+    def agent_condition(self, cond):
+        c = np.ascontiguousarray(np.broadcast_to(np.asarray(cond, np.uint8), (self.B, self.N)))
+        with torch.cuda.device(self.device):
+            L.check(L.lib().cm_env_agent_condition(self._h, c.ctypes.data, None), "cm_env_agent_condition")
+
+    def apply_agent_fault(self, kind, p, r=0.0, fault_step=0, tape_u=None):
+        """kind 'iid': iid_fault(n_agents, p_fault=p) (:290-292); kind 'GE': GE_fault(condition, p, r) (:294-301, one draw
+        per group as written).  tape_u: the uniforms (numpy, [B,N] / [B,2]) in tape mode, else Philox site 9 at fault_step."""
+        mode = {"iid": 1, "GE": 2}[kind]
+        keep = None if tape_u is None else torch.as_tensor(np.ascontiguousarray(tape_u, np.float32)).to(self.device)
+        with torch.cuda.device(self.device):
+            L.check(L.lib().cm_env_agent_fault(self._h, mode, float(p), float(r), L.ptr(keep), int(fault_step) & 0xFFFFFFFF,
+                                               L.current_stream()), "cm_env_agent_fault")
+            torch.cuda.current_stream().synchronize()
+
+    def comm_delays(self, dist_adj, link_loss, delay_th=None, old_delays=None):
+        """delays_init(adjacency, link_loss, delay_th) when old_delays is None, else calc_delays(adjacency, link_loss,
+        old_delays) (:271-286).  CUDA tensors [B,N,N] / [B,L,N,N] / [B,N,N] int32 -> delays [B,L,N,N] int32."""
+        Lh = link_loss.shape[1]
+        out = torch.empty(self.B, Lh, self.N, self.N, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            L.check(L.lib().cm_comm_delays(self.B, Lh, self.N, L.ptr(None if dist_adj is None else dist_adj.contiguous()),
+                                           L.ptr(link_loss.contiguous()),
+                                           L.ptr(None if old_delays is None else old_delays.contiguous()),
+                                           int(delay_th or 0), int(old_delays is None), L.ptr(out), L.current_stream()),
+                    "cm_comm_delays")
+        return out
+
     def set_state(self, **arrays):
+        if "agent_cond" in arrays:
+            self.agent_condition = arrays.pop("agent_cond")
+            if not arrays:
+                return
         keep = {k: np.ascontiguousarray(v) for k, v in arrays.items()}
         cs = L.EnvState(*[keep[k].ctypes.data if k in keep and keep[k].size else None for k in (
             "agent_pos", "prey_pos", "prey_alive", "visited", "step_count", "total_capture", "success", "ge_state",
@@ -284,6 +326,16 @@ class _WrapperBase:
         if self._single:
             return {i: [int(p[0, i, 0]), int(p[0, i, 1])] for i in range(self.n_agents)}
         return p
+
+    @property
+    def agent_condition(self):
+        """predator_prey.py:74: ones unless a fault model was applied (GridEnvBatch.apply_agent_fault)."""
+        c = self.batch.agent_condition
+        return c[0].astype(np.float64) if self.batch.B == 1 else c
+
+    @agent_condition.setter
+    def agent_condition(self, cond):
+        self.batch.agent_condition = cond
 
     def get_avail_actions(self):
         """All ones (predatorprey_wrapper.py:46-51)."""

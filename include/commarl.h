@@ -142,6 +142,20 @@ int cm_env_status(cm_env_t h);
 int cm_env_get_state(cm_env_t h, const cm_env_state *host);
 int cm_env_set_state(cm_env_t h, const cm_env_state *host);
 
+/* PP agent_condition (predator_prey.py:74,152,258): [B,N] bytes, 0 = the agent's moves are not applied; every env reset
+ * puts its row back to ones.  HOST pointers; either may be NULL.  Synchronises. */
+int cm_env_agent_condition(cm_env_t h, const uint8_t *set_host, uint8_t *get_host);
+/* The reference's dormant agent-fault models, applied to agent_condition (custom_implement/env_communication.py:290-301;
+ * never called by the reference's own code): mode 1 = iid_fault(n, p_fault = p); mode 2 = GE_fault(condition, p, r) as
+ * written (ONE draw for all good agents, ONE for all bad ones).  tape_u (DEVICE, [B,N] for mode 1, [B,2] for mode 2):
+ * the uniforms np.random.choice would consume, or NULL = Philox site 9 at (global env id, fault_step). */
+int cm_env_agent_fault(cm_env_t h, int32_t mode, float p, float r, const float *tape_u, uint32_t fault_step, void *stream);
+/* Link-delay counters (env_communication.py:271-286), a pure function of DEVICE arrays: init != 0 = delays_init(adjacency
+ * [B,N,N], link_loss [B,L,N,N], delay_th); init == 0 = calc_delays(adjacency, link_loss, old_delays [B,N,N]).
+ * delays [B,L,N,N] int32.  NULL adjacency / link_loss = ones. */
+int cm_comm_delays(int32_t B, int32_t L, int32_t N, const float *dist_adj, const float *link_loss, const int32_t *old_delays,
+                   int32_t delay_th, int32_t init, int32_t *delays, void *stream);
+
 /* Comm-DP policy weights (device pointers), reference state_dict names in comments
  * (SURVEY.md §8 a-16).  Linear weights are passed TRANSPOSED [in,out] (contiguous over the
  * output index) - the veneer keeps a transposed device copy; GCN weights are already [in,out]. */

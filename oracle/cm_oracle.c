@@ -157,6 +157,7 @@ typedef struct env_view {
     uint32_t *visited;
     int32_t *step_count, *total_capture, *success;
     uint8_t *ge_state;
+    uint8_t *cond;           /* agent_condition of this env, or NULL */
 } env_view;
 
 static int in_grid(const env_view *e, int r, int c) { return r >= 0 && r < e->S && c >= 0 && c < e->S; }
@@ -173,6 +174,7 @@ static void view_init(env_view *e, const cmo_cfg *cfg, cmo_state *st, int b) {
     e->total_capture = st->total_capture ? st->total_capture + b : NULL;
     e->success = st->success + b;
     e->ge_state = st->ge_state ? st->ge_state + (size_t)b * e->N * e->N : NULL;
+    e->cond = st->agent_cond ? st->agent_cond + (size_t)b * e->N : NULL;
 }
 
 /* rebuild the character grid (_full_obs) from positions: agents + live preys (+ walls) */
@@ -368,6 +370,7 @@ static void pp_reset(env_view *e, rng_ctx *rc) {
         }
     *e->step_count = 0;
     for (int j = 0; j < e->M; ++j) e->alive[j] = 1;
+    if (e->cond) memset(e->cond, 1, (size_t)e->N);                    /* __init_full_obs :152 */
 }
 
 /* Coverage.reset (:221-246) + __init_full_obs (:172-196); team split only colours cells */
@@ -437,7 +440,9 @@ static int pp_step(env_view *e, rng_ctx *rc, const int32_t *act, double *reward,
         if (a != 4) {
             moving++;
             int r = e->apos[2 * i], c = e->apos[2 * i + 1], nr = r + DR[a], nc = c + DC[a];
-            if (vacant(e, nr, nc)) {
+            /* :257-261: a vacant target moves the agent only if agent_condition[i] != 0 (otherwise its cell is
+             * cleared and re-marked by __update_agent_view: the agent stays where it is) */
+            if (vacant(e, nr, nc) && (!e->cond || e->cond[i] != 0)) {
                 e->grid[r * G + c] = C_EMPTY; e->grid[nr * G + nc] = C_AGENT;
                 e->apos[2 * i] = nr; e->apos[2 * i + 1] = nc;
             }

@@ -267,8 +267,10 @@ def split_tape(tape, scenario, env, L, reset_happened, channel):
     return out
 
 
-def record_env(ns, scenario, params, B, T, seed, channel='FC', max_path_length=None, p_random=0.5):
-    """Roll B independent reference envs for T steps through the reference VecEnvExecutor."""
+def record_env(ns, scenario, params, B, T, seed, channel='FC', max_path_length=None, p_random=0.5, agent_condition=None):
+    """Roll B independent reference envs for T steps through the reference VecEnvExecutor.
+    agent_condition [B,N] (PP): written into env.agent_condition after the initial reset - the gate of
+    predator_prey.py:258; the env itself sets it back to ones at every reset (:152), which the recording shows."""
     import importlib
     VecEnvExecutor = importlib.import_module('garage.sampler.vec_env_executor').VecEnvExecutor
     random.seed(seed)
@@ -297,7 +299,7 @@ def record_env(ns, scenario, params, B, T, seed, channel='FC', max_path_length=N
 
     rec = {k: [] for k in ('actions', 'prey_tape', 'spawn_tape', 'spawn_n', 'iid_u', 'ge_u', 'ge_init_u', 'reward', 'done',
                            'details', 'obs', 'agent_pos', 'prey_pos', 'prey_alive', 'prey_alive_info', 'visited',
-                           'total_capture', 'step_count', 'success', 'dist_adj', 'channels')}
+                           'total_capture', 'step_count', 'success', 'dist_adj', 'channels', 'agent_cond')}
 
     def push_state(lst_keys, snaps, obs):
         for k in lst_keys:
@@ -319,6 +321,10 @@ def record_env(ns, scenario, params, B, T, seed, channel='FC', max_path_length=N
             tape.first_call = False
             snaps.append(snapshot(envs[b], scenario))
             obs0.append(o)
+        if agent_condition is not None:
+            for b in range(B):
+                envs[b].agent_condition = np.asarray(agent_condition[b], dtype=np.float64).copy()
+            rec['agent_cond'].append(np.stack([np.asarray(e.agent_condition, dtype=np.uint8) for e in envs]))
         push_state(state_keys, snaps, obs0)
         init_tape = {k: np.stack([d[k] for d in init]) for k in init[0]}
 
@@ -338,6 +344,8 @@ def record_env(ns, scenario, params, B, T, seed, channel='FC', max_path_length=N
                 if scenario == 'pp':
                     pinfo.append(np.asarray(info['prey_alive'][0], dtype=np.uint8))
             rec['actions'].append(np.stack(acts))
+            if agent_condition is not None:
+                rec['agent_cond'].append(np.stack([np.asarray(e.agent_condition, dtype=np.uint8) for e in envs]))
             for k in ('prey_tape', 'spawn_tape', 'spawn_n', 'iid_u', 'ge_u', 'ge_init_u'):
                 rec[k].append(np.stack([d[k] for d in tapes]))
             rec['reward'].append(np.array(rew))
@@ -383,6 +391,46 @@ def record_ge(ns, n=6, hops=20, seed=7):
     u = np.stack([t.numpy() for t in tape.rands]).reshape(hops, 2, n, n)
     return dict(u=u.astype(np.float32), states=seq.numpy().astype(np.uint8), pgb=np.float32(0.0196 * 8),
                 pbg=np.float32(0.282))
+
+
+def record_faults_direct(ns):
+    """The dormant fault / delay helpers (env_communication.py:270-301) called directly.  np.random.choice draws
+    `random_sample(size)` from the legacy global generator, so re-seeding and calling random_sample gives the very
+    uniforms each call consumed."""
+    ec = ns.env_communication
+    out = {}
+    iid_u, iid_c, iid_p = [], [], []
+    for seed, n, p_fault in ((1, 4, 0.3), (2, 24, 0.1), (3, 72, 0.5), (4, 9, 0.0), (5, 9, 1.0)):
+        np.random.seed(seed)
+        u = np.random.random_sample(n)
+        np.random.seed(seed)
+        c = ec.iid_fault(n, p_fault)
+        iid_u.append(np.pad(u, (0, 72 - n))); iid_c.append(np.pad(c, (0, 72 - n), constant_values=-1)); iid_p.append((n, p_fault))
+    out['iid_u'], out['iid_cond'], out['iid_np'] = np.array(iid_u), np.array(iid_c, dtype=np.int64), np.array(iid_p, dtype=np.float64)
+    ge_in, ge_out, ge_u, ge_pr = [], [], [], []
+    rng = np.random.RandomState(11)
+    for seed, n, p, r in ((6, 8, 0.2, 0.3), (7, 8, 0.9, 0.05), (8, 24, 0.5, 0.5), (9, 24, 0.0196, 0.282), (10, 5, 0.5, 0.9)):
+        cond = (rng.rand(n) < 0.6).astype(np.int64)
+        np.random.seed(seed)
+        ug = np.random.random_sample(1)[0]
+        ub = np.random.random_sample(1)[0]
+        np.random.seed(seed)
+        new = ec.GE_fault(cond.copy(), p, r)
+        ge_in.append(np.pad(cond, (0, 24 - n), constant_values=-1)); ge_out.append(np.pad(new, (0, 24 - n), constant_values=-1))
+        ge_u.append((ug, ub)); ge_pr.append((n, p, r))
+    out['ge_in'], out['ge_out'] = np.array(ge_in, dtype=np.int64), np.array(ge_out, dtype=np.int64)
+    out['ge_u'], out['ge_npr'] = np.array(ge_u, dtype=np.float64), np.array(ge_pr, dtype=np.float64)
+    L, N, th = 2, 6, 7
+    adj = (rng.rand(N, N) < 0.6).astype(np.float32)
+    np.fill_diagonal(adj, 1)
+    links = [(rng.rand(L, N, N) < 0.7).astype(np.float32) for _ in range(4)]
+    d0 = ec.delays_init(adj, links[0], th)
+    seq = [d0]
+    for lk in links[1:]:
+        seq.append(ec.calc_delays(adj, lk, seq[-1][-1]))
+    out['delay_adj'], out['delay_links'], out['delay_th'] = adj, np.array(links), np.int64(th)
+    out['delays'] = np.array(seq, dtype=np.int64)                     # [4 calls, L, N, N]
+    return out
 
 
 def record_adj_ties(ns, seed=3):
@@ -735,7 +783,7 @@ def main():
         print(f'{name:28s} {os.path.getsize(path) / 1024:8.1f} KiB')
 
     fx = {}
-    if args.only and args.only.startswith(('ppo_step', 'variants_', 'ppo_math', 'adam', 'adj_ties_grid32')):
+    if args.only and args.only.startswith(('ppo_step', 'variants_', 'ppo_math', 'adam', 'adj_ties_grid32', 'faults_direct', 'env_pp_map10_cond')):
         return late(save, args)
     # config 1/2: PP map10 sen1 den.04 cap2 (full 200-step horizon, chasing so captures happen)
     fx['pp_map10_cap2'] = record_env(ns, 'pp', pp_params(10, 1, 0.04, 2), B=3, T=230, seed=1, p_random=0.35)
@@ -798,6 +846,10 @@ def late(save, args, ns=None):
     """Fixtures that do not need the env recordings of this run."""
     ns = ns or ref_loader.load_reference()
     save('adj_ties_grid32', lambda: record_adj_ties_grid32(ns))
+    save('faults_direct', lambda: record_faults_direct(ns))
+    save('env_pp_map10_cond', lambda: record_env(ns, 'pp', pp_params(10, 1, 0.04, 2, max_env_steps=12), B=4, T=30, seed=21,
+                                                 p_random=0.6, agent_condition=np.array([[1, 0, 1, 0], [0, 0, 0, 0],
+                                                                                          [1, 1, 1, 1], [0, 1, 1, 1]])))
     save('ppo_math', lambda: record_ppo_math(ns))
     save('adam', lambda: record_adam(ns))
     save('ppo_step', lambda: record_ppo_step())

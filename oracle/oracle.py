@@ -42,7 +42,7 @@ class Cfg(C.Structure):
 class State(C.Structure):
     _fields_ = [("agent_pos", C.c_void_p), ("prey_pos", C.c_void_p), ("prey_alive", C.c_void_p),
                 ("visited", C.c_void_p), ("step_count", C.c_void_p), ("total_capture", C.c_void_p),
-                ("success", C.c_void_p), ("ge_state", C.c_void_p), ("rng_step", C.c_void_p)]
+                ("success", C.c_void_p), ("ge_state", C.c_void_p), ("rng_step", C.c_void_p), ("agent_cond", C.c_void_p)]
 
 
 class Tape(C.Structure):
@@ -163,6 +163,7 @@ class OracleEnv:
         self.success = np.zeros(B, np.int32)
         self.ge_state = np.ones((B, N, N), np.uint8)
         self.rng_step = np.zeros(B, np.uint32)
+        self.agent_cond = np.ones((B, N), np.uint8)         # PP agent_condition (predator_prey.py:74,152,258)
         self.obs = np.zeros((B, N, self.d), np.float32)
         self.reward = np.zeros(B, np.float64)
         self.done = np.zeros(B, np.uint8)
@@ -172,7 +173,7 @@ class OracleEnv:
         self.prey_alive_info = np.zeros((B, M), np.uint8)
         self._st = State(*[_p(a) for a in (self.agent_pos, self.prey_pos, self.prey_alive, self.visited,
                                            self.step_count, self.total_capture, self.success, self.ge_state,
-                                           self.rng_step)])
+                                           self.rng_step, self.agent_cond)])
         self._out = Out(*[_p(a) for a in (self.obs, self.reward, self.done, self.details, self.dist_adj,
                                           self.channels, self.prey_alive_info)])
 
@@ -197,9 +198,57 @@ class OracleEnv:
             raise RuntimeError(f"cmo_step failed: {rc}")
         return self.obs, self.reward, self.done
 
+    def load_state(self, **arrays):
+        """Overwrite parts of the state in place (agent_pos, prey_pos, prey_alive, step_count, agent_cond ...)."""
+        for k, v in arrays.items():
+            getattr(self, k)[...] = v
+
     def visited_dense(self):
         cols = np.arange(self.S, dtype=np.uint32)
         return ((self.visited[:, :, None] >> cols[None, None, :]) & 1).astype(np.uint8)
+
+
+# --------------------------------------------------------------------------------------
+# dormant fault / delay helpers of custom_implement/env_communication.py:270-301 (SURVEY §8f-3): never called by the
+# reference's own code; restated literally and pinned by direct-call recordings (tests/golden/faults_direct.npz)
+# --------------------------------------------------------------------------------------
+def iid_fault(u, p_fault):
+    """env_communication.py:290-292: np.random.choice([0, 1], size=n, p=[p_fault, 1 - p_fault]) on the uniforms `u` the
+    legacy generator draws for it (choice = cdf.searchsorted(u, side='right')): 0 (faulty) iff u < p_fault."""
+    cdf = np.cumsum(np.array([p_fault, 1.0 - p_fault], np.float64))
+    cdf /= cdf[-1]
+    return np.array([0, 1])[np.searchsorted(cdf, np.asarray(u, np.float64), side="right")].astype(np.int64)
+
+
+def ge_fault(cond, u_good, u_bad, p, r):
+    """env_communication.py:294-301 AS WRITTEN: `size=(len(G_condition))` is the length of np.where's TUPLE (= 1), so ONE
+    draw decides all currently-good agents (stay good with 1 - p) and ONE all currently-bad ones (recover with r)."""
+    cond = np.asarray(cond)
+    new = np.zeros_like(cond)
+    g = 1 if u_good < 1.0 - p else 0              # np.random.choice([1, 0], size=1, p=[1 - p, p])
+    b = 1 if u_bad < r else 0                     # np.random.choice([1, 0], size=1, p=[r, 1 - r])
+    new[cond == 1] = g
+    new[cond == 0] = b
+    return new
+
+
+def delays_init(adjacency, link_loss, delay_th):
+    """env_communication.py:271-279.  adjacency [N,N], link_loss [L,N,N] -> [L,N,N]."""
+    delays = [np.where(adjacency == 0, delay_th, 1)]
+    for i, link in enumerate(link_loss[1:]):
+        delays.append(np.where(link == 0, delays[i] + 1, 1))
+    return np.array(delays)
+
+
+def calc_delays(adjacency, link_loss, old_delays):
+    """env_communication.py:281-286 with `old_delays` an [N,N] matrix (e.g. the last hop of the previous call): the
+    function has no caller in the reference; with the [L,N,N] array delays_init returns it would broadcast to
+    [L,L,N,N], so the per-matrix reading is the only shape-consistent one."""
+    loss = adjacency * link_loss
+    delays = [np.where(loss[0] == 0, old_delays + 1, 1)]
+    for i, l in enumerate(loss[1:]):
+        delays.append(np.where(l == 0, delays[i] + 1, 1))
+    return np.array(delays)
 
 
 # --------------------------------------------------------------------------------------

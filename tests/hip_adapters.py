@@ -41,6 +41,7 @@ class HipEnv:
         self.agent_pos, self.prey_pos, self.prey_alive = st["agent_pos"], st["prey_pos"], st["prey_alive"]
         self.visited, self.step_count, self.total_capture = st["visited"], st["step_count"], st["total_capture"]
         self.success, self.ge_state, self.rng_step = st["success"], st["ge_state"], st["rng_step"]
+        self.agent_cond = b.agent_condition
         self.obs = b.obs.cpu().numpy()
         self.reward = b.reward64.cpu().numpy()
         self.reward32 = b.reward.cpu().numpy()

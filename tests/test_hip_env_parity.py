@@ -34,6 +34,57 @@ def test_adjacency_ties_through_the_hip_env_step(hip):
     check_adjacency(drive_adjacency(hip.HipEnv, "adj_ties_grid32.npz", 32))
 
 
+def test_agent_faults_and_delays_direct(hip):
+    """cm_env_agent_fault / cm_comm_delays against the reference's own functions called directly
+    (tests/golden/faults_direct.npz: iid_fault, GE_fault incl. its one-draw-per-group quirk, delays_init, calc_delays),
+    then the production Philox stream (site 9) against the same rules applied to host-side Philox draws."""
+    import torch
+    from com_marl_amd import envs as E
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "faults_direct.npz"))
+    base = dict(load=2, max_env_steps=20, capture_reward=10, step_cost=0.1, rm=0, penalty=0, grid_size=30, Rsen=1,
+                n_gcn_layers=2, mode="train", trRcom=9, trpl=0)
+    for i in range(z["iid_u"].shape[0]):
+        n, p = int(z["iid_np"][i, 0]), float(z["iid_np"][i, 1])
+        env = E.GridEnvBatch("pp", dict(base, n_agents=n, n_preys=1), 3, device="cuda:0", seed=1, rng_mode="tape")
+        u = np.tile(z["iid_u"][i, :n].astype(np.float32), (3, 1))
+        if np.any(np.abs(z["iid_u"][i, :n] - p) < 1e-6):
+            continue                                       # a float32 copy of the uniform could flip a tie
+        env.apply_agent_fault("iid", p, tape_u=u)
+        np.testing.assert_array_equal(env.agent_condition, np.tile(z["iid_cond"][i, :n], (3, 1)))
+    for i in range(z["ge_u"].shape[0]):
+        n, p, r = int(z["ge_npr"][i, 0]), float(z["ge_npr"][i, 1]), float(z["ge_npr"][i, 2])
+        env = E.GridEnvBatch("pp", dict(base, n_agents=n, n_preys=1), 2, device="cuda:0", seed=1, rng_mode="tape")
+        env.agent_condition = np.tile(z["ge_in"][i, :n], (2, 1))
+        env.apply_agent_fault("GE", p, r, tape_u=np.tile(z["ge_u"][i].astype(np.float32), (2, 1)))
+        np.testing.assert_array_equal(env.agent_condition, np.tile(z["ge_out"][i, :n], (2, 1)))
+    # delays: init then three calc steps, batch of 2 identical problems
+    N, Lh = z["delay_adj"].shape[0], z["delay_links"].shape[1]
+    env = E.GridEnvBatch("pp", dict(base, n_agents=N, n_preys=1), 2, device="cuda:0", seed=1)
+    adj = torch.as_tensor(np.tile(z["delay_adj"], (2, 1, 1))).cuda()
+    links = [torch.as_tensor(np.tile(z["delay_links"][k], (2, 1, 1, 1))).cuda() for k in range(z["delay_links"].shape[0])]
+    d = env.comm_delays(adj, links[0], delay_th=int(z["delay_th"]))
+    np.testing.assert_array_equal(d.cpu().numpy()[1], z["delays"][0])
+    for k in range(1, len(links)):
+        d = env.comm_delays(adj, links[k], old_delays=d[:, -1].contiguous())
+        np.testing.assert_array_equal(d.cpu().numpy()[0], z["delays"][k])
+    # production stream: Philox site 9, counter (global env id, fault_step, 9, idx)
+    env = E.GridEnvBatch("pp", dict(base, n_agents=9, n_preys=1), 64, device="cuda:0", seed=77, env_id_offset=5)
+    env.apply_agent_fault("iid", 0.4, fault_step=3)
+    want = np.zeros((64, 9), np.int64)
+    for b in range(64):
+        us = [O.philox((5 + b, 3, 9, q), (77, 0)) for q in range(3)]
+        u = np.array([(int(w) >> 8) * (1.0 / 16777216.0) for q in range(3) for w in us[q]], np.float32)[:9]
+        want[b] = O.iid_fault(u, np.float32(0.4))
+    np.testing.assert_array_equal(env.agent_condition, want)
+    assert 0 < want.mean() < 1
+    env.apply_agent_fault("GE", 0.3, 0.6, fault_step=4)
+    got = env.agent_condition
+    for b in range(64):
+        x = O.philox((5 + b, 4, 9, 0), (77, 0))
+        ug, ub = np.float32((int(x[0]) >> 8) * (1.0 / 16777216.0)), np.float32((int(x[1]) >> 8) * (1.0 / 16777216.0))
+        np.testing.assert_array_equal(got[b], O.ge_fault(want[b], ug, ub, np.float32(0.3), np.float32(0.6)))
+
+
 def _lockstep(cfg_kwargs, steps, hip, seed=1234, check_every=1):
     """Same Philox stream, same random actions through oracle and HIP; compare everything."""
     cfg_o = O.make_cfg(**cfg_kwargs, rng_mode=O.RNG_PHILOX, seed=seed)

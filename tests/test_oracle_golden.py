@@ -47,9 +47,14 @@ def replay(path, make_env, check_every=1):
 
     env.reset(**tape_at("init_"))
     check_state(0, "after reset")
+    has_cond = "agent_cond" in z.files             # PP agent_condition set after the reset (predator_prey.py:258 gate)
+    if has_cond:
+        env.load_state(agent_cond=z["agent_cond"][0])
     for t in range(T):
         env.step(z["actions"][t], **tape_at("", t))
         where = f"step {t}"
+        if has_cond:                               # the env's own reset puts it back to ones (:152)
+            np.testing.assert_array_equal(env.agent_cond, z["agent_cond"][t + 1], err_msg=f"agent_cond {where}")
         np.testing.assert_array_equal(env.done, z["done"][t], err_msg=f"done {where}")
         np.testing.assert_array_equal(env.reward, z["reward"][t], err_msg=f"reward {where}")
         np.testing.assert_array_equal(env.details[:, :5], z["details"][t][:, :5], err_msg=f"details {where}")
@@ -126,17 +131,30 @@ def check_adjacency(results):
         assert got[d2 == 162].all() and not got[d2 > 162].any()
 
 
-class _OracleWithLoad(O.OracleEnv):
-    def load_state(self, **arrays):
-        for k, v in arrays.items():
-            getattr(self, k)[...] = v
-
-
 @pytest.mark.parametrize("fixture,grid", [("adj_ties.npz", 40), ("adj_ties_grid32.npz", 32)])
 def test_adjacency_ties(fixture, grid):
     """The oracle's env step emits exactly the reference's adjacency on the tie-heavy recordings: the integer rule
     dx^2+dy^2 <= 2*Rcom^2 == f32 cdist <= Rcom_th incl. exact ties."""
-    check_adjacency(drive_adjacency(_OracleWithLoad, fixture, grid))
+    check_adjacency(drive_adjacency(O.OracleEnv, fixture, grid))
+
+
+def test_fault_and_delay_helpers_direct():
+    """iid_fault / GE_fault / delays_init / calc_delays (env_communication.py:270-301; never called by the reference's own
+    code) against recordings of the functions called directly, on the uniforms each call consumed."""
+    z = np.load(os.path.join(GOLDEN, "faults_direct.npz"))
+    for i in range(z["iid_u"].shape[0]):
+        n, p = int(z["iid_np"][i, 0]), float(z["iid_np"][i, 1])
+        np.testing.assert_array_equal(O.iid_fault(z["iid_u"][i, :n], p), z["iid_cond"][i, :n])
+    for i in range(z["ge_u"].shape[0]):
+        n, p, r = int(z["ge_npr"][i, 0]), float(z["ge_npr"][i, 1]), float(z["ge_npr"][i, 2])
+        got = O.ge_fault(z["ge_in"][i, :n], z["ge_u"][i, 0], z["ge_u"][i, 1], p, r)
+        np.testing.assert_array_equal(got, z["ge_out"][i, :n])
+    d = O.delays_init(z["delay_adj"], z["delay_links"][0], int(z["delay_th"]))
+    np.testing.assert_array_equal(d, z["delays"][0])
+    for k in range(1, z["delays"].shape[0]):
+        d = O.calc_delays(z["delay_adj"], z["delay_links"][k], d[-1])
+        np.testing.assert_array_equal(d, z["delays"][k])
+    assert z["delays"].max() > int(z["delay_th"])     # a link stayed lost long enough to pass the threshold
 
 
 def test_philox_known_answers():
