@@ -48,7 +48,9 @@ def _train(rank, world, port):
     algo = CentralizedMAPPO(env_spec=env.spec, policy=pol, baseline=crit, max_path_length=MPL, discount=0.99,
                             center_adv=True, positive_adv=False, gae_lambda=0.97, policy_ent_coeff=0.1,
                             entropy_method="regularized", clip_grad_norm=0.05, optimization_n_minibatches=1,
-                            optimization_mini_epochs=3, device="cuda:0")
+                            optimization_mini_epochs=int(os.environ.get("COMMARL_DIST_STEPS", "3")), device="cuda:0")
+    if os.environ.get("COMMARL_DIST_NOCLIP"):
+        algo._lr_clip_range = 1e9                     # diagnostic: the surrogate without its clip (no gradient discontinuity)
     smp = CentralizedMAOnPolicyVectorizedSampler(algo, env, n_envs=B_UNION)
     smp.start_worker()
     paths = smp.obtain_samples(0, batch_size=B_UNION * 4 * MPL)
@@ -65,43 +67,61 @@ def _train(rank, world, port):
     out["grad_norm"] = algo.stats["GradNorm"]
     out["loss_after"] = algo.stats["LossAfter"]
     if world > 1:
+        import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
     return out
 
 
-def run_two_rank_case():
-    """Parent: start the two ranks as fresh processes (before this process touches the GPU), then train the union here
-    and compare."""
+def _compare(steps, noclip):
+    """One comparison: two fresh ranks vs the union trained in a fresh single process (all three are children)."""
     import tempfile
     tmp = tempfile.mkdtemp()
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    procs = [subprocess.Popen([sys.executable, "-m", "tests.dist_train_child", str(r), "2", str(port), tmp], cwd=ROOT)
+    env = dict(os.environ, COMMARL_DIST_STEPS=str(steps))
+    if noclip:
+        env["COMMARL_DIST_NOCLIP"] = "1"
+    procs = [subprocess.Popen([sys.executable, "-m", "tests.dist_train_child", str(r), "2", str(port), tmp], cwd=ROOT, env=env)
              for r in range(2)]
     rcs = [p.wait(timeout=600) for p in procs]
     assert rcs == [0, 0], f"rank exit codes {rcs}"
+    rc = subprocess.run([sys.executable, "-m", "tests.dist_train_child", "9", "1", "0", tmp], cwd=ROOT, env=env, timeout=600).returncode
+    assert rc == 0, f"union run exit code {rc}"
     ranks = [dict(np.load(os.path.join(tmp, f"rank{r}.npz"))) for r in range(2)]
-    ref = _train(0, 1, 0)
-    assert int(ranks[0]["n_paths"]) + int(ranks[1]["n_paths"]) == ref["n_paths"] == int(ranks[0]["n_union"])
+    ref = dict(np.load(os.path.join(tmp, "rank9.npz")))
+    assert int(ranks[0]["n_paths"]) + int(ranks[1]["n_paths"]) == int(ref["n_paths"]) == int(ranks[0]["n_union"])
     assert int(ranks[0]["n_paths"]) != int(ranks[1]["n_paths"])          # ragged shards: mean-of-means would differ
     worst = 0.0
     for k, v in ref.items():
         if not k.startswith(("pol.", "crit.")):
             continue
+        if os.environ.get("COMMARL_DIST_DEBUG"):
+            print(f"{k:70s} rank-vs-union {np.abs(ranks[0][k] - v).max():.3e}")
         np.testing.assert_array_equal(ranks[0][k], ranks[1][k], err_msg=f"replicas diverged: {k}")
-        # 3 Adam steps of lr 3e-4: a parameter moved by ~1e-3; agreement to summation order of the f32 gradient sums
-        np.testing.assert_allclose(ranks[0][k], v, rtol=0, atol=2e-6, err_msg=k)
+        # Adam steps of lr 3e-4: a parameter moved by ~1e-3; agreement to summation order of the f32 gradient sums
+        np.testing.assert_allclose(ranks[0][k], v, rtol=0, atol=2e-6, err_msg=f"{k} (steps={steps}, noclip={noclip})")
         worst = max(worst, float(np.abs(ranks[0][k] - v).max()))
     # clip-after-reduce: the reported norm is that of the GLOBAL gradient on every rank
-    np.testing.assert_allclose(float(ranks[0]["grad_norm"]), ref["grad_norm"], rtol=1e-4)
-    np.testing.assert_allclose(float(ranks[1]["grad_norm"]), ref["grad_norm"], rtol=1e-4)
+    np.testing.assert_allclose(float(ranks[0]["grad_norm"]), float(ref["grad_norm"]), rtol=1e-4)
+    np.testing.assert_allclose(float(ranks[1]["grad_norm"]), float(ref["grad_norm"]), rtol=1e-4)
     # GradNorm is recorded after the clip (centralized_ma_ppo.py:253-256): ~0.05 means the clip was active on every step,
     # so clipping before instead of after the reduce would have changed the parameters compared above
-    assert abs(ref["grad_norm"] - 0.05) < 1e-3, ref["grad_norm"]
-    return dict(n_paths=[int(ranks[0]["n_paths"]), int(ranks[1]["n_paths"])], max_param_diff=worst,
-                grad_norm=ref["grad_norm"])
+    assert abs(float(ref["grad_norm"]) - 0.05) < 1e-3, ref["grad_norm"]
+    return dict(n_paths=[int(ranks[0]["n_paths"]), int(ranks[1]["n_paths"])], max_param_diff=worst, grad_norm=float(ref["grad_norm"]))
+
+
+def run_two_rank_case():
+    """Two comparisons.  (a) the update as configured, two optimiser steps.  (b) five optimiser steps with PPO's ratio clip
+    switched off: min(r.A, clip(r).A) has a gradient discontinuity where a sample's ratio crosses 1 +- 0.1, so from the
+    third step on a 1e-8 parameter difference (float summation order) can flip one borderline sample in or out of the
+    gradient and move parameters by ~1e-5 - measured: 2.3e-5 after three clipped steps, 3e-8 after five unclipped ones.
+    That sensitivity is PPO's, on one GPU as on two; (b) shows the exchange step itself stays exact over a longer chain."""
+    a = _compare(2, False)
+    b = _compare(5, True)
+    return dict(n_paths=a["n_paths"], max_param_diff=max(a["max_param_diff"], b["max_param_diff"]), grad_norm=a["grad_norm"],
+                clipped_2_steps=a["max_param_diff"], unclipped_5_steps=b["max_param_diff"])
 
 
 if __name__ == "__main__":

@@ -21,7 +21,7 @@ CASES = {
     "env_wide_off": (dict(COMMARL_ENV_WIDE="0"), "narrow one-wave-per-env kernels for large teams at small batches"),
     "debug_library_env_goldens": (dict(COMMARL_LIB=os.path.join(ROOT, "com-marl_amd", "libcommarl_hip_dbg.so")),
                                   "range-checked (-DCM_BOUNDS) build: env goldens + Philox lock-step"),
-    "two_rank_train_once": ({}, "CentralizedMAPPO.train_once on 2 gloo ranks (both on GPU 0) == 1 process on the union"),
+    "two_rank_train_once": ({}, "CentralizedMAPPO.train_once on 2 gloo ranks (both on GPU 0) == 1 process on the union (2 clipped steps; 5 steps without the ratio clip)"),
 }
 
 

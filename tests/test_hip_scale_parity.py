@@ -195,8 +195,10 @@ def test_env_knob_branches_in_child_processes(case):
 
 def test_two_rank_train_once_equals_one_process_on_the_union():
     """The distributed branch of CentralizedMAPPO.train_once (algos.py: SUM losses, one all-reduce per optimiser step,
-    division by global counts, clip after the reduce) on two gloo ranks sharing GPU 0, ragged path shards 37 / 59 envs,
-    three optimiser steps: parameters == one process trained on the union (tests/dist_train_child.py)."""
+    division by global counts, clip after the reduce) on two gloo ranks sharing GPU 0, ragged path shards 37 / 59 envs:
+    parameters == one process trained on the union after two optimiser steps as configured and after five with PPO's
+    ratio clip off (its gradient discontinuity makes longer clipped chains sensitive to the last bit of a sum on any
+    number of GPUs - tests/dist_train_child.py)."""
     from tests.conftest import child_result
     res = child_result("two_rank_train_once")
     assert res["rc"] == 0, f"two-rank case failed:\n{res['tail']}"
