@@ -61,6 +61,12 @@ class ChunkStrides(C.Structure):
 MLP_MAX_LAYERS = 6
 
 
+class FwdSaves(C.Structure):
+    """cm_fwd_saves: device pointers of the activations the training forward stores (include/commarl.h)."""
+    _fields_ = [("a1", C.c_void_p), ("e", C.c_void_p), ("q", C.c_void_p), ("hw", C.c_void_p * 4), ("h", C.c_void_p * 4),
+                ("x1", C.c_void_p), ("x2", C.c_void_p), ("x3", C.c_void_p), ("out", C.c_void_p)]
+
+
 class MlpWeights(C.Structure):
     _fields_ = [("in_dim", C.c_int32), ("n_layers", C.c_int32), ("out_dim", C.c_int32 * MLP_MAX_LAYERS),
                 ("tanh_mask", C.c_int32), ("_pad", C.c_int32), ("wt", C.c_void_p * MLP_MAX_LAYERS),
@@ -114,6 +120,10 @@ _SIGNATURES = {
                                         C.c_void_p, C.c_void_p, C.c_void_p]),
     "cm_linear_wgrad": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p]),
+    "cm_policy_forward_saved": (C.c_int, [C.POINTER(PolicyWeights), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.POINTER(FwdSaves), C.c_void_p]),
+    "cm_critic_forward_saved": (C.c_int, [C.POINTER(CriticWeights), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.POINTER(FwdSaves), C.c_void_p]),
     "cm_env_agent_condition": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cm_env_agent_fault": (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_uint32, C.c_void_p]),
     "cm_comm_delays": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,

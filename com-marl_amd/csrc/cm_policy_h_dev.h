@@ -340,6 +340,30 @@ __device__ __forceinline__ void stage_obs(const FwdArgs &a, const Planes X, int 
     }
 }
 
+// Training forward: a finished LDS tile leaves once, coalesced, as f32 [rows][W] at dst + row0 * W.  Called in the phase
+// that CONSUMES the tile (it is stable there); planes are joined to hi + 2^-12 lo - exactly the value the rest of the
+// network saw.
+template <int W, int TPBW>
+__device__ __forceinline__ void dump_planes(const Planes P, float *__restrict__ dst, size_t row0, int rows, int tid) {
+    if (!dst) return;
+    constexpr int Q4 = W / 4;
+    for (int k = tid; k < rows * Q4; k += TPBW) {
+        const int r = k / Q4, q = k - r * Q4;
+        const v4h h = *reinterpret_cast<const v4h *>(P.hi + (size_t)r * P.stride + 4 * q);
+        const v4h l = *reinterpret_cast<const v4h *>(P.lo + (size_t)r * P.stride + 4 * q);
+        *reinterpret_cast<float4 *>(dst + (row0 + r) * W + 4 * q) = make_float4(join2(h[0], l[0]), join2(h[1], l[1]), join2(h[2], l[2]), join2(h[3], l[3]));
+    }
+}
+template <int W, int TPBW>
+__device__ __forceinline__ void dump_f32(const float *src, int stride, float *__restrict__ dst, size_t row0, int rows, int tid) {
+    if (!dst) return;
+    constexpr int Q4 = W / 4;
+    for (int k = tid; k < rows * Q4; k += TPBW) {
+        const int r = k / Q4, q = k - r * Q4;
+        *reinterpret_cast<float4 *>(dst + (row0 + r) * W + 4 * q) = *reinterpret_cast<const float4 *>(src + (size_t)r * stride + 4 * q);
+    }
+}
+
 // ---- LDS map (bytes), shared by every path; regions that are never live together overlay each other -------------
 //   R1  planes 128 wide  : enc1 output, then the A tile of the aggregation (f32 [rows][NPA]), then head layer 1 output
 //   EP  planes 64 wide   : E
@@ -416,6 +440,8 @@ __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, c
     if (a.stop == 2) return;
     if (quad_path || big) l_enc2.template run<true, OUT_PLANES>(Ap, Ep, nullptr, 0, RT, wave, lane);
     else l_enc2.template run<true, OUT_PLANES | OUT_F32>(Ap, Ep, EF, SF, RT, wave, lane);
+    const size_t grow0 = (size_t)s0 * N;                     // first global agent row of this workgroup
+    if (quad_path && a.sv_on) dump_planes<128, TPBW>(Ap, a.sv_a1, grow0, rows, tid);           // encoder hidden layer
     LayerH<EMB, HEAD == 0 ? H1 : DH, NW> l_x1;               // first head layer (policy 64 -> 128, critic 64 -> 64)
     LayerH<H1, H2, NW> l_h2;
     if (quad_path) l_x1.load(HEAD == 0 ? ph.h1_p : chd.d1_p, HEAD == 0 ? ph.b1 : chd.b1, wave, lane);
@@ -434,8 +460,13 @@ __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, c
             if (L > 1) l_g.load(tw.gcn_p + LayerH<EMB, EMB, NW>::PACK_U4, nullptr, wave, lane);
         }
         if (HEAD == 0) l_h2.load(ph.h2_p, ph.b2, wave, lane);
+        if (a.sv_on) dump_planes<64, TPBW>(Ep, a.sv_e, grow0, rows, tid);
         lds_barrier();
         if (a.stop == 4) return;
+        if (a.sv_on) {
+            dump_planes<64, TPBW>(Tp, a.sv_q, grow0, rows, tid);
+            if (L > 0) dump_f32<64, TPBW>(HW0, SF, a.sv_hw[0], grow0, rows, tid);
+        }
         const int tw_ = (RT > 1) ? (wave & 1) : 0, ch = wave >> 1;
         const int rb = 16 * tw_;
         const v4f sc = scores_tile_h(Tp, Ep, rb + c, rb + c, g);
@@ -509,10 +540,12 @@ __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, c
             }
             lds_barrier();
             if (a.stop == 61 + l) return;
+            if (a.sv_on && l < 4) dump_planes<64, TPBW>(Hp, a.sv_h[l], grow0, rows, tid);      // hop output (last: + residual)
             if (!last) {
                 l_g.template run<false, OUT_F32>(Hp, Hp, (l & 1) ? HW0 : HW1, SF, RT, wave, lane);     // H.Wg_{l+1}
                 if (l + 2 < L) l_g.load(tw.gcn_p + (size_t)(l + 2) * LayerH<EMB, EMB, NW>::PACK_U4, nullptr, wave, lane);
                 lds_barrier();
+                if (a.sv_on && l + 1 < 4) dump_f32<64, TPBW>((l & 1) ? HW0 : HW1, SF, a.sv_hw[l + 1], grow0, rows, tid);
             }
         }
     } else {
@@ -833,15 +866,20 @@ __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, c
         l_x1.template run<true, OUT_PLANES>(Hp, Ap, nullptr, 0, RT, wave, lane);             // 64 -> 128 into R1
         lds_barrier();
         l_h2.template run<true, OUT_PLANES>(Ap, Tp, nullptr, 0, RT, wave, lane);             // 128 -> 64 into T
+        if (quad_path && a.sv_on) dump_planes<128, TPBW>(Ap, a.sv_x1, grow0, rows, tid);
         const int A = ph.n_act;
         LayerH<H3, 16, NW> l_h4;                             // 32 -> n_act (<= 8) logits, zero-padded to one feature tile
         l_h4.load(ph.h4_p, ph.b4, wave, lane, A);
         lds_barrier();
         l_h3.template run<true, OUT_PLANES>(Tp, Gp, nullptr, 0, RT, wave, lane);             // 64 -> 32 into EP
+        if (quad_path && a.sv_on) dump_planes<64, TPBW>(Tp, a.sv_x2, grow0, rows, tid);
         lds_barrier();
         if (a.stop == 7) return;
         l_h4.template run<false, OUT_F32>(Gp, Gp, LG, SLG, RT, wave, lane);                  // logits f32 into T
+        if (quad_path && a.sv_on) dump_planes<32, TPBW>(Gp, a.sv_x3, grow0, rows, tid);
         lds_barrier();
+        if (quad_path && a.sv_on && a.sv_out)
+            for (int k = tid; k < rows * A; k += TPBW) { const int r = k / A, cc = k - r * A; a.sv_out[(grow0 + r) * A + cc] = LG[(size_t)r * SLG + cc]; }
         for (int r = tid; r < rows; r += TPBW) {
             float lg[MAX_ACT], p[MAX_ACT];
             const float *x = LG + (size_t)r * SLG;
@@ -892,11 +930,13 @@ __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, c
         float *XF = reinterpret_cast<float *>(lds + lm.r1);                                  // critic: tanh(x1) f32 [rows][SF] in R1
         l_x1.template run<true, OUT_F32>(Hp, Hp, XF, SF, RT, wave, lane);
         lds_barrier();
+        if (quad_path && a.sv_on) dump_f32<64, TPBW>(XF, SF, a.sv_x1, grow0, rows, tid);
         for (int r = tid; r < rows; r += TPBW) {
             const float *x = XF + (size_t)r * SF;
             float acc = chd.b2 ? chd.b2[0] : 0.0f;
             for (int k = 0; k < DH; ++k) acc = fmaf(x[k], chd.w2t[k], acc);
             rs[r] = acc;
+            if (quad_path && a.sv_on && a.sv_out) a.sv_out[grow0 + r] = acc;
         }
         lds_barrier();
         for (int e = tid; e < envs; e += TPBW) {

@@ -206,6 +206,41 @@ int critic_forward_mfma(const cm_critic_weights *w, int32_t S, const float *obs,
 
 }  // namespace cm
 
+static bool saved_shape_ok(int N, int L, int d) { return N == 4 && cm::mf::pick_epb(4) * 4 <= 32 && L <= 4 && L >= 0 && d <= 96; }
+static void set_saves(cm::mf::FwdArgs &a, const cm_fwd_saves *sv) {
+    a.sv_on = 1;
+    a.sv_a1 = sv->a1; a.sv_e = sv->e; a.sv_q = sv->q; a.sv_x1 = sv->x1; a.sv_x2 = sv->x2; a.sv_x3 = sv->x3; a.sv_out = sv->out;
+    for (int l = 0; l < 4; ++l) { a.sv_hw[l] = sv->hw[l]; a.sv_h[l] = sv->h[l]; }
+}
+
+extern "C" int cm_policy_forward_saved(const cm_policy_weights *w, int32_t S, const float *obs, const float *adj, const float *chan,
+                                       float *attn, const cm_fwd_saves *sv, void *stream) {
+    using namespace cm;
+    if (!w || !obs || !sv) return set_error(CM_ERR_ARG, "cm_policy_forward_saved: null argument");
+    if (S <= 0) return CM_OK;
+    if (!w->mfma_pack || !policy_shape_ok(w) || !saved_shape_ok(w->n_agents, w->n_hops, w->d)) return 1;
+    mf::FwdArgs a{};
+    a.S = S; a.N = w->n_agents; a.d = w->d; a.L = w->n_hops;
+    a.obs = obs; a.adj = adj; a.chan = chan; a.attn = attn; a.no_residual = w->no_residual;
+    set_saves(a, sv);
+    const mf::PackLayout lo = mf::pack_layout(mf::kpad_of(w->d), w->n_hops, true);
+    return policy_forward_h(w, w->mfma_pack + lo.total, a, stream);
+}
+
+extern "C" int cm_critic_forward_saved(const cm_critic_weights *w, int32_t S, const float *obs, const float *adj, const float *chan,
+                                       float *attn, float *values, const cm_fwd_saves *sv, void *stream) {
+    using namespace cm;
+    if (!w || !obs || !sv || !values) return set_error(CM_ERR_ARG, "cm_critic_forward_saved: null argument");
+    if (S <= 0) return CM_OK;
+    if (!w->mfma_pack || !critic_shape_ok(w) || !saved_shape_ok(w->n_agents, w->n_hops, w->d)) return 1;
+    mf::FwdArgs a{};
+    a.S = S; a.N = w->n_agents; a.d = w->d; a.L = w->n_hops;
+    a.obs = obs; a.adj = adj; a.chan = chan; a.attn = attn; a.values = values; a.no_residual = w->no_residual;
+    set_saves(a, sv);
+    const mf::PackLayout lo = mf::pack_layout(mf::kpad_of(w->d), w->n_hops, false);
+    return critic_forward_h(w, w->mfma_pack + lo.total, a, stream);
+}
+
 extern "C" size_t cm_policy_pack_bytes(const cm_policy_weights *w) {
     if (!cm::policy_shape_ok(w)) return 0;
     return cm::mf::pack_layout(cm::mf::kpad_of(w->d), w->n_hops, true).total * sizeof(float) + cm::policy_pack_h_bytes(w->d, w->n_hops, true);

@@ -50,6 +50,12 @@ struct FwdArgs {
     int env_id_offset, greedy, no_residual;
     int32_t *actions;
     float *probs, *attn, *values;
+    // training forward (cm_policy_forward_saved / cm_critic_forward_saved; teams-of-4 path of cm_policy_h_dev.h): when sv_on,
+    // every activation the backward pass needs leaves LDS once, as f32 [R = S*N rows, width]: encoder hidden (128), E (64),
+    // Q (64), per hop H.Wg_l (64) and the hop's output (64; the last one includes the residual), head hidden layers
+    // (128 | 64 | 32; critic: 64), logits [R, n_act] or the critic's per-agent value [R]
+    int sv_on;
+    float *sv_a1, *sv_e, *sv_q, *sv_hw[4], *sv_h[4], *sv_x1, *sv_x2, *sv_x3, *sv_out;
     int stop;          // diagnostic: return after phase `stop` (0 = run everything); COMMARL_FWD_STOP
     unsigned long long *probe;   // diagnostic (COMMARL_FWD_PROBE): [blocks][NPROBE] shader-clock stamps of thread 0
 };

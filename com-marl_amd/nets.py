@@ -273,6 +273,143 @@ def masked_aggregate(attn, dist_adj, channels, hop, hw, bias):
 
 
 # ---------------------------------------------------------------------------------------------
+# whole-network training forward (teams of 4): ONE fused launch that stores what the backward needs, and a hand-written
+# backward chain over the C-ABI kernels - no per-layer forward kernels, no gradient-accumulation adds from autograd
+# ---------------------------------------------------------------------------------------------
+def _lin_bwd(x2, w, layout, dy2, y2, want_dx, has_bias):
+    """cm_linear_act_backward on 2-D contiguous tensors -> (dx | None, dw, db | None)."""
+    R, K = x2.shape
+    O = dy2.shape[1]
+    dx = torch.empty_like(x2) if want_dx else None
+    dw = torch.zeros_like(w)
+    db = torch.zeros(O, dtype=torch.float32, device=w.device) if has_bias else None
+    with torch.cuda.device(w.device):
+        L.check(L.lib().cm_linear_act_backward(R, K, O, L.ptr(x2), L.ptr(w), layout, L.ptr(dy2), L.ptr(y2), L.ptr(dx), L.ptr(dw),
+                                               L.ptr(db), L.current_stream()), "cm_linear_act_backward")
+    return dx, dw, db
+
+
+def _fused_train_ok(net, obs):
+    return (obs.is_cuda and torch.is_grad_enabled() and net._n_agents == 4 and 1 <= len(net.gcn_layers) <= 4
+            and net._dec_obs_dim <= 96 and len(net.encoder._layers) == 1
+            and os.environ.get("COMMARL_FUSED_TRAIN", "1") != "0" and os.environ.get("COMMARL_POLICY_KERNEL", "")[:1] not in ("f", "v"))
+
+
+class _FusedNetFn(torch.autograd.Function):
+    """CommBaseNet trunk + head as ONE forward launch (cm_policy_forward_saved / cm_critic_forward_saved: the rollout
+    kernel with stores of every activation the backward needs) and a hand-written backward chain:
+    head layers <- residual <- L x (masked aggregation <- H.Wg) <- attention softmax <- linear_in <- encoder, each link one
+    C-ABI kernel (cm_linear_act_backward, cm_masked_agg_backward, cm_attention_backward).  Returns logits [S,N,A]
+    (policy) or per-agent values [S,N] (critic); the attention matrix comes back as a non-differentiable second output
+    (the reference detaches nothing here, but no loss term reads it)."""
+
+    @staticmethod
+    def forward(ctx, net, obs, adj, ch, *params):
+        N, Lh, d = net._n_agents, len(net.gcn_layers), net._dec_obs_dim
+        S = obs.shape[0]
+        R = S * N
+        dev = obs.device
+        policy = hasattr(net, "categorical_output_layer")
+        z = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)   # noqa: E731
+        obs2 = obs.reshape(R, d).contiguous()
+        t = dict(a1=z(R, 128), e=z(R, 64), q=z(R, 64), hw=[z(R, 64) for _ in range(Lh)], h=[z(R, 64) for _ in range(Lh)])
+        if policy:
+            A = net._action_dim
+            t.update(x1=z(R, 128), x2=z(R, 64), x3=z(R, 32), out=z(R, A))
+        else:
+            t.update(x1=z(R, 64), out=z(R))
+        attn = z(S, N, N)
+        sv = L.FwdSaves()
+        sv.a1, sv.e, sv.q, sv.x1, sv.out = (t[k].data_ptr() for k in ("a1", "e", "q", "x1", "out"))
+        if policy:
+            sv.x2, sv.x3 = t["x2"].data_ptr(), t["x3"].data_ptr()
+        for l in range(Lh):
+            sv.hw[l], sv.h[l] = t["hw"][l].data_ptr(), t["h"][l].data_ptr()
+        adj_c = None if adj is None else adj.contiguous()
+        ch_c = None if ch is None else ch.contiguous()
+        with torch.cuda.device(dev):
+            if policy:
+                w = net._weights_struct()
+                rc = L.lib().cm_policy_forward_saved(C.byref(w), S, L.ptr(obs2), L.ptr(adj_c), L.ptr(ch_c), L.ptr(attn),
+                                                     C.byref(sv), L.current_stream())
+            else:
+                w = net._struct_from(net._packed())
+                w.mfma_pack = None if net._mfma is None else net._mfma.data_ptr()
+                vals = z(S)
+                rc = L.lib().cm_critic_forward_saved(C.byref(w), S, L.ptr(obs2), L.ptr(adj_c), L.ptr(ch_c), L.ptr(attn),
+                                                     L.ptr(vals), C.byref(sv), L.current_stream())
+        if rc == 1:
+            raise L.CommarlError("no saved-forward instantiation for this shape (caller should have checked _fused_train_ok)")
+        L.check(rc, "cm_*_forward_saved")
+        ctx.net, ctx.t, ctx.obs2, ctx.adj, ctx.ch, ctx.attn, ctx.policy = net, t, obs2, adj_c, ch_c, attn, policy
+        ctx.names = [n for n, _ in net.named_parameters()]
+        ctx.mark_non_differentiable(attn)
+        out = t["out"].view(S, N, -1) if policy else t["out"].view(S, N)
+        return out, attn
+
+    @staticmethod
+    def backward(ctx, d_out, _d_attn):
+        net, t, obs2, adj, ch, attn = ctx.net, ctx.t, ctx.obs2, ctx.adj, ctx.ch, ctx.attn
+        N, Lh = net._n_agents, len(net.gcn_layers)
+        R = obs2.shape[0]
+        S = R // N
+        P = dict(net.named_parameters())
+        g = {}
+        if ctx.policy:
+            hd = net.categorical_output_layer
+            lins = [l.linear for l in hd._layers] + [hd._output_layers[0].linear]
+            pre = ["categorical_output_layer._layers.%d.linear" % i for i in range(3)] + ["categorical_output_layer._output_layers.0.linear"]
+            acts = [t["h"][Lh - 1], t["x1"], t["x2"], t["x3"]]          # inputs of the four head layers
+            d = d_out.reshape(R, -1).contiguous()
+            for i in (3, 2, 1, 0):                                       # y of layer i = input of layer i + 1 (tanh), none for the logits
+                d, g[pre[i] + ".weight"], g[pre[i] + ".bias"] = _lin_bwd(acts[i], lins[i].weight, 0, d, None if i == 3 else acts[i + 1],
+                                                                          True, True)
+        else:
+            mm = net.baseline_aggregator._mean_module
+            l1, l2 = mm._layers[0].linear, mm._output_layers[0].linear
+            pre = "baseline_aggregator._mean_module."
+            d = d_out.reshape(R, 1).contiguous()
+            d, g[pre + "_output_layers.0.linear.weight"], g[pre + "_output_layers.0.linear.bias"] = _lin_bwd(t["x1"], l2.weight, 0, d, None, True, True)
+            d, g[pre + "_layers.0.linear.weight"], g[pre + "_layers.0.linear.bias"] = _lin_bwd(t["h"][Lh - 1], l1.weight, 0, d, t["x1"], True, True)
+        # d = gradient wrt the trunk output x = E + H_L (or H_L)
+        e, q = t["e"], t["q"]
+        dE = d if net.residual else None                                 # residual: the same gradient flows into E
+        dH, d_attn = d, None
+        with torch.cuda.device(obs2.device):
+            for l in reversed(range(Lh)):
+                gl = net.gcn_layers[l]
+                out_l = (t["h"][l] - e) if (l == Lh - 1 and net.residual) else t["h"][l]      # tanh output of hop l
+                da, dhw = torch.empty_like(attn), torch.empty_like(e)
+                dgb = torch.zeros(64, dtype=torch.float32, device=e.device) if gl.bias is not None else None
+                chan_ptr, stride = None, 0
+                if ch is not None:
+                    chan_ptr, stride = ch.data_ptr() + 4 * l * N * N, ch.shape[1] * N * N
+                L.check(L.lib().cm_masked_agg_backward(S, N, 64, L.ptr(attn), L.ptr(adj), chan_ptr, stride, L.ptr(t["hw"][l]),
+                                                       L.ptr(out_l), L.ptr(dH), L.ptr(da), L.ptr(dhw), L.ptr(dgb),
+                                                       L.current_stream()), "cm_masked_agg_backward")
+                d_attn = da if d_attn is None else d_attn.add_(da)
+                hin = t["h"][l - 1] if l > 0 else e
+                dhin, g["gcn_layers.%d.weight" % l], _ = _lin_bwd(hin, gl.weight, 1, dhw, None, True, False)
+                if gl.bias is not None:
+                    g["gcn_layers.%d.bias" % l] = dgb
+                if l > 0:
+                    dH = dhin
+                else:
+                    dE = dhin if dE is None else dE.add_(dhin)          # (dE aliases d: its last reader, hop Lh-1, is done)
+            dq, de = torch.empty_like(q), torch.empty_like(e)
+            L.check(L.lib().cm_attention_backward(S, N, 64, L.ptr(q), L.ptr(e), L.ptr(attn), L.ptr(d_attn), L.ptr(dq), L.ptr(de),
+                                                  L.current_stream()), "cm_attention_backward")
+        dE.add_(de)
+        deq, g["attention_layer.linear_in.weight"], _ = _lin_bwd(e, net.attention_layer.linear_in.weight, 0, dq, None, True, False)
+        dE.add_(deq)
+        enc1, enc2 = net.encoder._layers[0].linear, net.encoder._output_layers[0].linear
+        da1, g["encoder._output_layers.0.linear.weight"], g["encoder._output_layers.0.linear.bias"] = _lin_bwd(t["a1"], enc2.weight, 0, dE, e, True, True)
+        _, g["encoder._layers.0.linear.weight"], g["encoder._layers.0.linear.bias"] = _lin_bwd(obs2, enc1.weight, 0, da1, t["a1"], False, True)
+        ctx.t = None                                                     # free the saved activations
+        return (None, None, None, None) + tuple(g.get(n) for n in ctx.names)
+
+
+# ---------------------------------------------------------------------------------------------
 # trunk
 # ---------------------------------------------------------------------------------------------
 def _as_dev(x, device):
@@ -452,9 +589,12 @@ class CommCategoricalMLPPolicy(CommBaseNet):
     # -- autograd path (PPO update) --------------------------------------------------------------
     def _probs(self, obs_n, avail_actions_n, dist_adj, channels):
         lead, S, obs, adj, ch = self._flatten(obs_n, dist_adj, channels)
-        E, H, M = self.trunk(obs, adj, ch)
-        x = E + H if self.residual else H
-        logits = self.categorical_output_layer(x)
+        if _fused_train_ok(self, obs) and len(self.categorical_output_layer._layers) == 3:
+            logits, M = _FusedNetFn.apply(self, obs, adj, ch, *self.parameters())     # one forward launch + hand-written backward
+        else:
+            E, H, M = self.trunk(obs, adj, ch)
+            x = E + H if self.residual else H
+            logits = self.categorical_output_layer(x)
         probs = torch.softmax(logits, dim=-1)
         if avail_actions_n is not None:
             probs = probs * avail_actions_n.reshape(S, self._n_agents, -1)
@@ -653,6 +793,11 @@ class CommBaseCritic(CommBaseNet):
 
     def _values_grad(self, obs_n, dist_adj, channels):
         lead, S, obs, adj, ch = self._flatten(obs_n, dist_adj, channels)
+        if _fused_train_ok(self, obs) and len(self.baseline_aggregator._mean_module._layers) == 1:
+            per_agent, _ = _FusedNetFn.apply(self, obs, adj, ch, *self.parameters())  # [S,N] per-agent means
+            ag = self.baseline_aggregator
+            ls = ag._init_std if ag._min_std_param is None else ag._init_std.clamp(min=ag._min_std_param)
+            return per_agent.sum(-1).reshape(*lead), ls.exp()
         E, H, _ = self.trunk(obs, adj, ch)
         x = E + H if self.residual else H
         mean, std = self.baseline_aggregator(x)

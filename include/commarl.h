@@ -210,6 +210,24 @@ int cm_policy_forward(const cm_policy_weights *w, int32_t n_samples, const float
 int cm_critic_forward(const cm_critic_weights *w, int32_t n_samples, const float *obs, const float *dist_adj,
                       const float *channels, float *values, void *stream);
 
+/* Training forward (PPO update): the same fused forward, which additionally stores every activation the backward pass
+ * needs ONCE, as f32 [R = S * n_agents rows, width] (the value the rest of the network saw): what torch's autograd would
+ * keep layer by layer through ~20 separate kernels.  Pointers that are NULL are skipped.
+ *   a1 [R,128] encoder hidden layer     e [R,64] encoder output E     q [R,64] attention query E.Wa^T
+ *   hw[l] [R,64] H_l.Wg_l               h[l] [R,64] hop l's output tanh(A_l.hw[l] + b_l); the LAST hop's entry includes the
+ *                                       residual (x = E + H_L, comm_categorical_mlp_policy.py:74-77) unless no_residual
+ *   x1, x2, x3  head hidden layers: policy [R,128], [R,64], [R,32]; critic x1 [R,64] only
+ *   out         policy: logits [R, n_act] (before softmax / avail mask); critic: per-agent value [R] (before the sum)
+ * attn [S,N,N] is written as in cm_policy_forward.  Returns 1 - nothing done - when there is no saved-forward
+ * instantiation for the shape (built for teams of 4, n_hops <= 4, obs dim <= 96): the caller then runs layer by layer. */
+typedef struct cm_fwd_saves {
+    float *a1, *e, *q, *hw[4], *h[4], *x1, *x2, *x3, *out;
+} cm_fwd_saves;
+int cm_policy_forward_saved(const cm_policy_weights *w, int32_t n_samples, const float *obs, const float *dist_adj,
+                            const float *channels, float *attn, const cm_fwd_saves *sv, void *stream);
+int cm_critic_forward_saved(const cm_critic_weights *w, int32_t n_samples, const float *obs, const float *dist_adj,
+                            const float *channels, float *attn, float *values, const cm_fwd_saves *sv, void *stream);
+
 /* One rollout step in ONE launch: cm_policy_forward over the B envs of `h` followed, inside the same workgroups, by
  * cm_env_step on the sampled actions (which travel through LDS and are also written to `actions`): what one iteration
  * of the sampler loop does (centralized_ma_on_policy_vectorized_sampler.py:133-141).  Arguments and results are those

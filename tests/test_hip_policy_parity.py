@@ -334,3 +334,58 @@ def test_operand_pack_path_equals_plain_weight_path(n_agents, d, torch_cuda):
     with torch.no_grad():
         p_ref, _ = pol._probs(obs, None, None, None)
     np.testing.assert_allclose(p2.cpu().numpy(), p_ref.cpu().numpy(), **TOL)
+
+
+@pytest.mark.parametrize("d,hops,residual,masks", [(21, 2, True, False), (21, 2, True, True), (53, 1, False, True), (77, 3, True, True),
+                                                  (29, 2, False, False)])
+def test_fused_training_path_vs_per_layer_autograd(d, hops, residual, masks, torch_cuda, monkeypatch):
+    """Teams of 4: the whole-network training path (ONE forward launch that stores the activations, cm_*_forward_saved, +
+    the hand-written backward chain of nets._FusedNetFn) against the per-layer autograd path of the same nets
+    (COMMARL_FUSED_TRAIN=0): policy probabilities / critic values 1e-5, every parameter gradient to 1e-4 relative + 1e-5
+    of the tensor's largest entry (the two forwards differ in the last bits: f16-split MFMA vs f32 MFMA per layer)."""
+    torch = torch_cuda
+    from com_marl_amd import nets
+    from com_marl_amd.envs import EnvSpec, _Box, _Discrete
+    N, P, T = 4, 7, 13                                     # 91 samples: ragged last workgroup (8 envs per workgroup)
+    spec = EnvSpec(_Box(np.zeros(N * d), np.ones(N * d)), _Discrete(5))
+    torch.manual_seed(d + hops)
+    pol = nets.CommCategoricalMLPPolicy(spec, n_agents=N, n_gcn_layers=hops, residual=residual, device="cuda:0")
+    crit = nets.CommBaseCritic(spec, n_agents=N, n_gcn_layers=hops, residual=residual, device="cuda:0")
+    for net in (pol, crit):
+        for n_, p_ in net.named_parameters():
+            if n_.endswith("bias"):
+                torch.nn.init.uniform_(p_, -0.2, 0.2)     # non-zero biases so their handling is pinned
+    g = torch.Generator().manual_seed(5)
+    obs = torch.rand(P, T, N * d, generator=g).cuda()
+    adj = ch = None
+    if masks:
+        adj = (torch.rand(P, T, N, N, generator=g) < 0.7).float().cuda()
+        adj[..., torch.arange(N), torch.arange(N)] = 1.0
+        ch = (torch.rand(P, T, hops, N, N, generator=g) < 0.8).float().cuda()
+    avail = (torch.rand(P, T, N * 5, generator=g) < 0.85).float().cuda()
+    avail.view(P, T, N, 5)[..., 0] = 1.0
+    actions = torch.randint(0, 5, (P, T, N), generator=g).cuda()
+    wts = torch.randn(P, T, generator=g).cuda()
+    returns = torch.randn(P, T, generator=g).cuda()
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("COMMARL_FUSED_TRAIN", mode)
+        pol.zero_grad(); crit.zero_grad()
+        probs, attn = pol._probs(obs, avail, adj, ch)
+        dist = torch.distributions.Categorical(probs=probs)
+        loss = ((dist.log_prob(actions).sum(-1) + 0.1 * dist.entropy().mean(-1)) * wts).sum()
+        loss.backward()
+        closs = crit.compute_loss(obs, returns, adj, ch)
+        closs.backward()
+        res[mode] = dict(probs=probs.detach().cpu().numpy(), attn=attn.detach().cpu().numpy(), closs=float(closs.detach()),
+                         gp={n_: p_.grad.cpu().numpy().copy() for n_, p_ in pol.named_parameters()},
+                         gc={n_: p_.grad.cpu().numpy().copy() for n_, p_ in crit.named_parameters() if p_.grad is not None})
+    a, b = res["1"], res["0"]
+    np.testing.assert_allclose(a["probs"], b["probs"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(a["attn"], b["attn"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(a["closs"], b["closs"], rtol=1e-5)
+    assert set(a["gc"]) == set(b["gc"]) and set(a["gp"]) == set(b["gp"])
+    for key in ("gp", "gc"):
+        for n_ in b[key]:
+            scale = max(1e-6, float(np.abs(b[key][n_]).max()))
+            np.testing.assert_allclose(a[key][n_], b[key][n_], rtol=1e-4, atol=1e-5 * scale, err_msg=f"{key} {n_}")
