@@ -51,10 +51,13 @@ class CentralizedMAPPO:
         self._check_entropy_configuration(entropy_method, center_adv, stop_entropy_gradient, policy_ent_coeff)
         if use_softplus_entropy or self._maximum_entropy or stop_entropy_gradient:
             raise NotImplementedError("only the runners' entropy settings ('regularized' / 'no_entropy') are built")
-        opt = optimizer or torch.optim.Adam
-        bopt = baseline_optimizer or torch.optim.Adam
-        # torch.optim.Adam (foreach=False) is the same update as the vendored torch-1.9 Adam
-        # (my_optimizer/_functional.py:72-98): pinned by tests against the reference's optimiser.
+        # default: the multi-tensor Adam of optim.py (two launches per step, clip folded in); it and torch.optim.Adam are
+        # the same update as the vendored torch-1.9 Adam (my_optimizer/_functional.py:72-98): pinned by tests against the
+        # reference's optimiser.
+        from .optim import Adam as FusedAdam
+        on_gpu = next(policy.parameters()).is_cuda
+        opt = optimizer or (FusedAdam if on_gpu else torch.optim.Adam)
+        bopt = baseline_optimizer or (FusedAdam if on_gpu else torch.optim.Adam)
         self._optimizer = opt(policy.parameters(), lr=policy_lr, eps=1e-5)
         self._baseline_optimizer = bopt(baseline.parameters(), lr=policy_lr, eps=1e-5)
         self._optimization_n_minibatches = optimization_n_minibatches
@@ -325,10 +328,16 @@ class CentralizedMAPPO:
                 else:
                     self._baseline_loss(o, ret_mb, da, ch).backward()
                     (loss_sum / n_valid).backward()
-                if self._clip_grad_norm is not None:                                 # policy only (:253-255)
-                    torch.nn.utils.clip_grad_norm_(self.policy.parameters(), self._clip_grad_norm)
-                grad_norm.append(self.policy.grad_norm())
-                self._optimizer.step()                                               # _optimize (:606-610)
+                if hasattr(self._optimizer, "_norm"):                               # optim.Adam: clip + update in two launches
+                    mx = float("inf") if self._clip_grad_norm is None else float(self._clip_grad_norm)
+                    pre = self._optimizer.step(max_norm=mx)                          # policy only (:253-255)
+                    # the reference records the norm AFTER the clip (:256): |g| * min(1, max / (|g| + 1e-6)), kept on the device
+                    grad_norm.append(pre * torch.clamp(mx / (pre + 1e-6), max=1.0))
+                else:
+                    if self._clip_grad_norm is not None:
+                        torch.nn.utils.clip_grad_norm_(self.policy.parameters(), self._clip_grad_norm)
+                    grad_norm.append(self.policy.grad_norm())
+                    self._optimizer.step()                                           # _optimize (:606-610)
                 self._baseline_optimizer.step()
         torch.cuda.synchronize(obs.device)
         epoch_time = time.time() - t_opt
@@ -342,7 +351,8 @@ class CentralizedMAPPO:
         avg_return = perf["AverageReturn"]
         self.stats = dict(perf, LossBefore=loss_before, LossAfter=loss_after,
                           dLoss=loss_before - loss_after, KLBefore=kl_before, KL=kl, Entropy=entropy,
-                          GradNorm=float(np.mean(grad_norm)) if grad_norm else 0.0, EpochTime=epoch_time,
+                          GradNorm=(float(torch.stack([torch.as_tensor(g, dtype=torch.float32, device=obs.device) for g in grad_norm]).mean())
+                                    if grad_norm else 0.0), EpochTime=epoch_time,
                           TrainOnceTime=time.time() - t_start, MaxPathLength=T,
                           EnvSteps=int(valids.sum().item()),
                           GPUMemoryMax=torch.cuda.max_memory_allocated(self._dev()) / 1024 ** 3)     # :372-383 (GiB)

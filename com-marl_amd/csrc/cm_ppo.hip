@@ -392,9 +392,69 @@ __global__ void gae_kernel(int P, int T, const float *__restrict__ rewards, cons
     for (int t = 0; t < T; ++t) a[t] = (a[t] - m32) * inv;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Multi-tensor Adam (+ gradient-norm clip) for the ~17 + ~15 small parameter tensors of the policy / critic: ONE launch
+// for the norm, ONE for the update, instead of ~6 framework kernels per tensor and a host sync per tensor norm.
+// The update is the vendored torch-1.9 Adam of the reference (com_marl/torch/algos/my_optimizer/_functional.py:72-98):
+//   m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g g;  p -= (lr / (1 - b1^t)) m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+// and the clip is torch.nn.utils.clip_grad_norm_ (centralized_ma_ppo.py:253-255): g *= min(1, max_norm / (|g| + 1e-6)),
+// written back so that p.grad holds the clipped gradient as it does in the reference.
+// ---------------------------------------------------------------------------------------------
+struct TensorTable { float *p[40]; float *g[40]; float *m[40]; float *v[40]; long n[40]; int count; };
+
+__global__ __launch_bounds__(256) void multi_norm_kernel(TensorTable t, float *norm_sq) {
+    float acc = 0.0f;
+    const long stride = (long)gridDim.x * blockDim.x, i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int k = 0; k < t.count; ++k)
+        for (long i = i0; i < t.n[k]; i += stride) { const float g = t.g[k][i]; acc = fmaf(g, g, acc); }
+    __shared__ float red[256];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+    if (threadIdx.x == 0) atomicAdd(norm_sq, red[0]);
+}
+
+__global__ __launch_bounds__(256) void multi_adam_kernel(TensorTable t, const float *norm_sq, float *norm_sq_next, float max_norm, float lr,
+                                                        float b1, float b2, float eps, float bc1, float sqrt_bc2) {
+    float coef = 1.0f;
+    if (norm_sq) { const float c = max_norm / (sqrtf(*norm_sq) + 1e-6f); coef = c < 1.0f ? c : 1.0f; }
+    const float step_size = lr / bc1;
+    const long stride = (long)gridDim.x * blockDim.x, i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int k = 0; k < t.count; ++k)
+        for (long i = i0; i < t.n[k]; i += stride) {
+            float g = t.g[k][i];
+            if (norm_sq) { g *= coef; t.g[k][i] = g; }
+            const float m = t.m[k][i] * b1 + (1.0f - b1) * g;
+            const float v = t.v[k][i] * b2 + (1.0f - b2) * g * g;
+            t.m[k][i] = m; t.v[k][i] = v;
+            const float denom = sqrtf(v) / sqrt_bc2 + eps;
+            t.p[k][i] = t.p[k][i] - step_size * (m / denom);
+        }
+    if (norm_sq_next && blockIdx.x == 0 && threadIdx.x == 0) *norm_sq_next = 0.0f;     // the slot the NEXT step accumulates into
+}
+
 }  // namespace cm
 
 using namespace cm;
+
+extern "C" int cm_multi_adam_step(int32_t n, float *const *params, float *const *grads, float *const *exp_avg, float *const *exp_avg_sq,
+                                  const int64_t *sizes, float *norm_sq, float *norm_sq_next, float max_norm, float lr, float beta1,
+                                  float beta2, float eps, int32_t step, void *stream) {
+    if (n < 0 || n > 40) return set_error(CM_ERR_ARG, "cm_multi_adam_step: at most 40 tensors per call");
+    if (n == 0) return CM_OK;
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !sizes || step < 1) return set_error(CM_ERR_ARG, "cm_multi_adam_step: bad argument");
+    TensorTable t{};
+    t.count = n;
+    for (int k = 0; k < n; ++k) { t.p[k] = params[k]; t.g[k] = grads[k]; t.m[k] = exp_avg[k]; t.v[k] = exp_avg_sq[k]; t.n[k] = (long)sizes[k]; }
+    const hipStream_t st = (hipStream_t)stream;
+    if (norm_sq) hipLaunchKernelGGL(multi_norm_kernel, dim3(64), dim3(256), 0, st, t, norm_sq);
+    const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(multi_adam_kernel, dim3(64), dim3(256), 0, st, t, (const float *)norm_sq, norm_sq_next, max_norm, lr, beta1, beta2, eps,
+                       (float)(1.0 - pow((double)beta1, (double)step)), (float)sqrt(1.0 - pow((double)beta2, (double)step)));
+    (void)bc1; (void)bc2;
+    CM_HIP(hipGetLastError());
+    return CM_OK;
+}
 
 static size_t agg_lds_fwd(int N, int E) { const int epb = agg_epb(N), rows = epb * N; return ((size_t)rows * (N | 1) + (size_t)rows * (E + 4)) * 4; }
 static size_t agg_lds_bwd(int N, int E) {

@@ -1,0 +1,75 @@
+"""Adam for the policy / critic parameter sets as TWO launches per step (cm_multi_adam_step: one for the gradient norm, one
+for clip + update of every tensor) instead of ~6 framework kernels and a host sync per tensor.
+
+Same update rule, defaults and state layout as the reference's vendored torch-1.9 Adam
+(com_marl/torch/algos/my_optimizer/adam.py:56-120, _functional.py:72-98; state keys ``step`` / ``exp_avg`` /
+``exp_avg_sq``), so ``state_dict()`` interchanges with ``torch.optim.Adam``.  ``step(max_norm=...)`` folds
+``torch.nn.utils.clip_grad_norm_`` (centralized_ma_ppo.py:253-255) into the same launches and returns the pre-clip norm
+as a DEVICE tensor - nothing in an optimiser step waits for the host."""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+class Adam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
+        if weight_decay != 0 or amsgrad:
+            raise NotImplementedError("the runners use plain Adam (no weight decay, no amsgrad)")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False))
+        self._norm = None
+
+    @torch.no_grad()
+    def step(self, closure=None, max_norm=None):
+        """-> pre-clip gradient norm (device scalar tensor) when max_norm is given, else None."""
+        assert closure is None
+        out = None
+        for group in self.param_groups:
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            dev = ps[0].device
+            if dev.type != "cuda":
+                raise L.CommarlError("com_marl_amd.optim.Adam updates CUDA parameters (there is no CPU path)")
+            b1, b2 = group["betas"]
+            for p in ps:
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] = int(st["step"]) + 1
+            steps = {int(self.state[p]["step"]) for p in ps}
+            assert len(steps) == 1, "parameters of one group step together"
+            step = steps.pop()
+            grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in ps]
+            for p, g in zip(ps, grads):
+                if g is not p.grad:
+                    p.grad = g
+            n = len(ps)
+            arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])          # noqa: E731
+            sizes = (C.c_int64 * n)(*[p.numel() for p in ps])
+            norm_ptr = next_ptr = None
+            if max_norm is not None:
+                if self._norm is None or self._norm.device != dev:
+                    self._norm = torch.zeros(2, dtype=torch.float32, device=dev)
+                cur = step & 1
+                norm_ptr = self._norm.data_ptr() + 4 * cur
+                next_ptr = self._norm.data_ptr() + 4 * (1 - cur)
+                out = self._norm[cur]
+            if n > 40:
+                raise L.CommarlError("cm_multi_adam_step takes at most 40 tensors per parameter group")
+            with torch.cuda.device(dev):
+                L.check(L.lib().cm_multi_adam_step(
+                    n, arr(ps), arr(grads), arr([self.state[p]["exp_avg"] for p in ps]),
+                    arr([self.state[p]["exp_avg_sq"] for p in ps]), sizes, norm_ptr, next_ptr,
+                    float(max_norm if max_norm is not None else 0.0), float(group["lr"]), float(b1), float(b2),
+                    float(group["eps"]), step, L.current_stream()), "cm_multi_adam_step")
+            # the kernel wrote through raw pointers: tell torch (and the nets' weight-pack cache, which keys on the version
+            # counters) that the parameters changed
+            for p in ps:
+                torch.autograd.graph.increment_version(p)
+                if max_norm is not None:
+                    torch.autograd.graph.increment_version(p.grad)
+        return None if out is None else out.sqrt()
