@@ -136,6 +136,8 @@ _SIGNATURES = {
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cm_multi_adam_step": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_void_p]),
+    "cm_ppo_surrogate": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cm_discount_returns": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p,
                                       C.c_void_p]),
     "cm_gae": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int32,

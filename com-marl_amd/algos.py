@@ -26,6 +26,40 @@ from . import _lib as L
 from .sampler import CentralizedMAOnPolicyVectorizedSampler, PathBatch, tabular
 
 
+class _SurrogateFn(torch.autograd.Function):
+    """-(sum over valid steps of the clipped surrogate + entropy bonus) from the policy logits in one launch
+    (cm_ppo_surrogate: the ~30 elementwise / reduction launches of :390-438 + :540-589 and as many again in their
+    autograd); the gradient wrt the logits is produced by the same launch.  Returns (total f32, count int64)."""
+
+    @staticmethod
+    def forward(ctx, logits, actions, old_ll, adv, valids, clip, ent_coeff, add_entropy):
+        P, T, N, A = logits.shape
+        dev = logits.device
+        lg = logits.contiguous()
+        need = logits.requires_grad
+        dl = torch.empty_like(lg) if need else None
+        total = torch.empty((), dtype=torch.float64, device=dev)
+        count = torch.empty((), dtype=torch.int64, device=dev)
+        with torch.cuda.device(dev):
+            L.check(L.lib().cm_ppo_surrogate(P, T, N, A, L.ptr(lg), L.ptr(actions.contiguous()), L.ptr(old_ll.contiguous()),
+                                             L.ptr(adv.contiguous()), L.ptr(valids), float(clip), float(ent_coeff), int(add_entropy),
+                                             L.ptr(total), L.ptr(count), L.ptr(dl), L.current_stream()), "cm_ppo_surrogate")
+        ctx.dl = dl
+        ctx.mark_non_differentiable(count)
+        return total.to(torch.float32), count
+
+    @staticmethod
+    def backward(ctx, g_total, _g_count):
+        dl, ctx.dl = ctx.dl, None
+        return (dl.mul_(g_total),) + (None,) * 7
+
+
+def _fused_loss_ok(policy, obs, avail_actions, actions, valids):
+    import os
+    return (obs.is_cuda and avail_actions is None and hasattr(policy, "_logits") and policy._action_dim <= 8
+            and actions.dtype == torch.int32 and valids.dtype == torch.int32 and os.environ.get("COMMARL_FUSED_LOSS", "1") != "0")
+
+
 def _dist_ready():
     from .dist import is_distributed
     return is_distributed()
@@ -188,6 +222,11 @@ class CentralizedMAPPO:
             advantages = self._advantages(rewards, baselines, valids)
         if old_ll is None:
             old_ll = self._old_log_likelihood(obs, actions, dist_adjs, channels)
+        if _fused_loss_ok(self.policy, obs, avail_actions, actions, valids):
+            logits = self.policy._logits(obs, dist_adjs, channels)                   # [P,T,N,A]
+            total, count = _SurrogateFn.apply(logits, actions, old_ll, advantages, valids, self._lr_clip_range,
+                                              self._policy_ent_coeff, self._entropy_regularzied)
+            return (total, count) if not reduce else total / count
         probs, _ = self.policy._probs(obs, avail_actions, dist_adjs, channels)      # one trunk pass for both terms
         dist_n = Categorical(probs=probs)
         entropies = dist_n.entropy().mean(-1)                                        # policy.entropy (:121-126)

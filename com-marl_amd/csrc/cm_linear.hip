@@ -277,6 +277,10 @@ __global__ __launch_bounds__(TPB, (MAXT == 8 ? 2 : 1)) void bwd_kernel(long R, i
 }  // namespace lin
 }  // namespace cm
 
+namespace cm {
+int linear_bwd_stream(long R, int K, int O, const float *x, const float *w, int layout, const float *dy, const float *y,
+                      float *dx, float *dw, float *db, void *stream);   // cm_linear_bwd.hip: widths 32 / 64 / 128
+}
 using namespace cm;
 
 extern "C" int cm_linear_act_forward(int64_t R, int32_t K, int32_t O, const float *x, const float *w, int32_t w_layout,
@@ -301,6 +305,7 @@ extern "C" int cm_linear_act_backward(int64_t R, int32_t K, int32_t O, const flo
     if (K < 1 || O < 1 || K > 128 || O > 128) return set_error(CM_ERR_ARG, "cm_linear_act_backward: 1 <= in, out <= 128 required");
     if (w_layout != 0 && w_layout != 1) return set_error(CM_ERR_ARG, "cm_linear_act_backward: w_layout must be 0 ([out,in]) or 1 ([in,out])");
     if (R <= 0) return CM_OK;
+    if (const int rc = linear_bwd_stream(R, K, O, x, w, w_layout, dy, y, dx, dw, db, stream); rc != 1) return rc;
     const int OT = (O + 15) / 16, KT = (K + 15) / 16, NT = OT * KT;
     const size_t lds = ((size_t)lin::ROWS * (OT * 16 + 16) + (size_t)lin::ROWS * (KT * 16 + 16)) * sizeof(float);
     const long chunks = (R + lin::ROWS - 1) / lin::ROWS;

@@ -1,0 +1,346 @@
+// cm_linear_bwd.hip - streaming backward of one dense layer for widths 32 / 64 / 128 (every hidden layer of the nets):
+//
+//   dz = dy * act'(y);  dx = dz.W;  dW += dz^T.x (or x^T.dz);  db += colsum(dz)      reads dy, y, x once; writes dx once
+//
+// (reference: the autograd of nn.Linear + tanh in garage/torch/modules/multi_headed_mlp_module.py:134-149,
+// GraphConvolutionModule's H.W graph_conv_module.py:63, AttentionModule.linear_in attention_module.py:36.)
+//
+// The first version of this kernel (lin::bwd_kernel in cm_linear.hip, kept for the ragged widths: observation, logits)
+// staged a chunk through registers, waited, computed, waited: two workgroups per CU, ~1.3 TB/s.  This one is built
+// around the load path:
+//   * one persistent 8-wave workgroup per CU walks 64-row chunks; chunk t+1 arrives by LDS-DMA
+//     (global_load_lds_dwordx4, no registers) into the second buffer while chunk t is on the matrix pipe;
+//   * an LDS-DMA writes 1 KiB contiguously, so the tiles are unpadded rows; bank conflicts of the row-strided operand
+//     reads are removed by XOR-swizzling the 16-byte chunk index inside a row - applied to the per-lane SOURCE address
+//     on the way in and to the chunk index on every read;
+//   * the weight gradient is split by ROWS across waves (wave w: rows 16 (w/2) .. +15, half of the B tiles), over
+//     column-permuted tiles (tile u of a 64-wide operand = columns 4c + u), so that ONE ds_read_b128 per operand feeds
+//     the four tiles of a k-step; partial sums live in accumulators for the life of the workgroup and are reduced
+//     through LDS, then one float atomic per element per workgroup;
+//   * dx is computed transposed (weights as the A operand) so that a lane ends with four consecutive input features:
+//     one 16-byte store per tile.
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "cm_internal.h"
+
+namespace cm {
+namespace lin2 {
+
+constexpr int TPB = 512, NW = 8, ROWS = 64;
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// swizzle of the 16-byte chunk index inside row r of a W-wide tile (W / 4 chunks per row; rows of 32 floats cover
+// half of the 64 banks, so there the row's parity picks the half and the remaining bits do the swizzle)
+template <int W>
+__device__ __forceinline__ int swz(int r) { return W == 32 ? ((r >> 1) & 7) : (r & 15); }
+
+// float offset of 16-byte chunk j of row r
+template <int W>
+__device__ __forceinline__ int chunk_at(int r, int j) { return (r * (W / 4) + (j ^ swz<W>(r))) * 4; }
+
+// issue this wave's LDS-DMA loads of a [ROWS x W] tile to LDS byte address lds_addr (rows past `rows` re-read the last valid row; the caller zeroes them)
+template <int W>
+__device__ __forceinline__ void issue_tile(unsigned lds_addr, const float *__restrict__ src, long r0, int rows, int wave, int lane) {
+    constexpr int CH = W / 4, NI = W / 32;                 // chunks per row; wave-instructions per wave
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int inst = wave * NI + i, p = inst * 64 + lane;
+        const int r = p / CH, slot = p % CH;
+        const int rr = r < rows ? r : rows - 1;
+        const float *g = src + (r0 + rr) * W + 4 * (slot ^ swz<W>(r));
+        // hipcc orders every later ds_read behind a builtin LDS-DMA (s_waitcnt vmcnt(0) before the first operand read of
+        // the chunk being computed - no overlap left); as an asm statement the DMA is outside its bookkeeping and the
+        // kernel waits for it explicitly, before the barrier that hands the buffer over
+        const unsigned dst_b = __builtin_amdgcn_readfirstlane(lds_addr + (unsigned)(inst * 1024));
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(g), "s"(dst_b) : "memory");
+    }
+}
+
+// column of element c of permuted tile u of a W-wide operand
+template <int W>
+__device__ __forceinline__ int col_of(int u, int c) { return W == 32 ? 2 * c + u : 64 * (u >> 2) + 4 * c + (u & 3); }
+
+// the NU values of row r that lane column c feeds to tiles u0 .. u0 + NU - 1
+template <int W, int NU>
+__device__ __forceinline__ void load_cols(const float *tile, int r, int c, int u0, float (&out)[NU]) {
+    if constexpr (W == 128) {
+#pragma unroll
+        for (int h = 0; h < NU / 4; ++h) {
+            const float4 v = *reinterpret_cast<const float4 *>(tile + chunk_at<W>(r, 16 * ((u0 >> 2) + h) + c));
+            out[4 * h + 0] = v.x; out[4 * h + 1] = v.y; out[4 * h + 2] = v.z; out[4 * h + 3] = v.w;
+        }
+    } else if constexpr (W == 64) {
+        if constexpr (NU == 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(tile + chunk_at<W>(r, c));
+            out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+        } else {
+            const float2 v = *reinterpret_cast<const float2 *>(tile + chunk_at<W>(r, c) + u0);
+            out[0] = v.x; out[1] = v.y;
+        }
+    } else {
+        if constexpr (NU == 2) {
+            const float2 v = *reinterpret_cast<const float2 *>(tile + chunk_at<W>(r, c >> 1) + 2 * (c & 1));
+            out[0] = v.x; out[1] = v.y;
+        } else {
+            out[0] = tile[chunk_at<W>(r, c >> 1) + 2 * (c & 1) + u0];
+        }
+    }
+}
+
+template <int KT, int OT, int ACT, int LAYOUT>
+__global__ __launch_bounds__(TPB) void bwd_kernel(long R, const float *__restrict__ X, const float *__restrict__ W,
+                                                  const float *__restrict__ DY, const float *__restrict__ Yv,
+                                                  float *__restrict__ DX, float *__restrict__ DW, float *__restrict__ DB) {
+    constexpr int K = 16 * KT, O = 16 * OT;
+    constexpr int ZF = ROWS * O, XF = ROWS * K, BUF = ZF + XF;
+    constexpr int WA = LAYOUT == 0 ? O : K, WB = LAYOUT == 0 ? K : O;   // dW is [WA][WB]
+    constexpr int NA = WA / 16, NBH = WB / 32;                          // A tiles; B tiles of this wave's half
+    constexpr int NKT = KT / 2;                                         // dx column tiles per wave
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *Ys = lds + 2 * BUF;
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)lds;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
+    const int rg = wave >> 1, hb = wave & 1;
+
+    v4f acc[NA][NBH];
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < NBH; ++j) acc[i][j] = (v4f){ 0.f, 0.f, 0.f, 0.f };
+    float zsum[LAYOUT == 0 ? NA : NBH];
+#pragma unroll
+    for (float &z : zsum) z = 0.0f;
+
+    // dx: row tile rg, input-feature tiles kt = hb * NKT + i; wf[i][4 oq + u] = W(k = 16 kt + c, o = 16 oq + 4 g + u)
+    float wf[NKT][4 * OT];
+    if (DX) {
+#pragma unroll
+        for (int i = 0; i < NKT; ++i) {
+            const int k = 16 * (hb * NKT + i) + c;
+#pragma unroll
+            for (int e = 0; e < 4 * OT; ++e) {
+                const int o = 16 * (e >> 2) + 4 * g + (e & 3);
+                wf[i][e] = LAYOUT == 0 ? W[(size_t)o * K + k] : W[(size_t)k * O + o];
+            }
+        }
+    }
+
+    const long n_chunks = (R + ROWS - 1) / ROWS;
+    long ch = blockIdx.x;
+    int cb = 0;
+    // dz = dy * (1 - y^2) in place, and zero rows past the end of the last chunk (the DMA re-read a valid row there)
+    auto finish_tile = [&](float *buf, int rows) {
+        float *Zs = buf, *Xs = buf + ZF;
+        if (ACT) {
+#pragma unroll
+            for (int i = 0; i < ZF / (4 * TPB); ++i) {
+                const int p = 4 * (tid + i * TPB);
+                float4 z = *reinterpret_cast<float4 *>(Zs + p);
+                const float4 y = *reinterpret_cast<const float4 *>(Ys + p);
+                z.x *= 1.0f - y.x * y.x; z.y *= 1.0f - y.y * y.y; z.z *= 1.0f - y.z * y.z; z.w *= 1.0f - y.w * y.w;
+                if (p >= rows * O) z = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4 *>(Zs + p) = z;
+            }
+        } else if (rows < ROWS) {
+            for (int p = rows * O + tid; p < ZF; p += TPB) Zs[p] = 0.0f;
+        }
+        if (rows < ROWS)
+            for (int p = rows * K + tid; p < XF; p += TPB) Xs[p] = 0.0f;
+    };
+    auto issue = [&](float *buf, long chunk) {
+        const long r0 = chunk * ROWS;
+        const int rows = (int)min((long)ROWS, R - r0);
+        const unsigned b = lds_base + (unsigned)((buf - lds) * sizeof(float));
+        issue_tile<O>(b, DY, r0, rows, wave, lane);
+        issue_tile<K>(b + ZF * (unsigned)sizeof(float), X, r0, rows, wave, lane);
+        if (ACT) issue_tile<O>(lds_base + 2 * BUF * (unsigned)sizeof(float), Yv, r0, rows, wave, lane);
+    };
+    if (ch < n_chunks) {
+        issue(lds, ch);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int rows = (int)min((long)ROWS, R - ch * ROWS);
+        finish_tile(lds, rows);
+        __syncthreads();
+    }
+    for (; ch < n_chunks; ch += gridDim.x, cb ^= 1) {
+        const long next = ch + gridDim.x;
+        float *cur = lds + cb * BUF, *nxt = lds + (cb ^ 1) * BUF;
+        if (next < n_chunks) issue(nxt, next);
+        const float *Zs = cur, *Xs = cur + ZF;
+        const float *As = LAYOUT == 0 ? Zs : Xs, *Bs = LAYOUT == 0 ? Xs : Zs;
+        const long r0 = ch * ROWS;
+        const int rows = (int)min((long)ROWS, R - r0);
+        // ---- weight gradient: rows 16 rg .. +15 in four k-steps ----
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int r = 16 * rg + 4 * s + g;
+            float a[NA], b[NBH];
+            load_cols<WA, NA>(As, r, c, 0, a);
+            load_cols<WB, NBH>(Bs, r, c, hb * NBH, b);
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+#pragma unroll
+                for (int j = 0; j < NBH; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            if (DB) {
+                if constexpr (LAYOUT == 0) {
+                    if (hb == 0) {
+#pragma unroll
+                        for (int i = 0; i < NA; ++i) zsum[i] += a[i];
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NBH; ++j) zsum[j] += b[j];
+                }
+            }
+        }
+        // ---- input gradient, transposed: D[k][row] = sum_o W(k, o) dz[row][o] ----
+        if (DX) {
+            v4f d[NKT];
+#pragma unroll
+            for (int i = 0; i < NKT; ++i) d[i] = (v4f){ 0.f, 0.f, 0.f, 0.f };
+            const int r = 16 * rg + c;
+#pragma unroll
+            for (int oq = 0; oq < OT; ++oq) {
+                const float4 z = *reinterpret_cast<const float4 *>(Zs + chunk_at<O>(r, 4 * oq + g));
+#pragma unroll
+                for (int i = 0; i < NKT; ++i) {
+                    d[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][4 * oq + 0], z.x, d[i], 0, 0, 0);
+                    d[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][4 * oq + 1], z.y, d[i], 0, 0, 0);
+                    d[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][4 * oq + 2], z.z, d[i], 0, 0, 0);
+                    d[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][4 * oq + 3], z.w, d[i], 0, 0, 0);
+                }
+            }
+            if (r < rows) {
+#pragma unroll
+                for (int i = 0; i < NKT; ++i)
+                    *reinterpret_cast<float4 *>(DX + (size_t)(r0 + r) * K + 16 * (hb * NKT + i) + 4 * g) =
+                        make_float4(d[i][0], d[i][1], d[i][2], d[i][3]);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                   // chunk `next` has landed; every wave is done with `cur`
+        if (next < n_chunks) {
+            const int nrows = (int)min((long)ROWS, R - next * ROWS);
+            if (ACT || nrows < ROWS) {
+                finish_tile(nxt, nrows);
+                __syncthreads();
+            }
+        }
+    }
+
+    // ---- reduce the weight-gradient partial sums of the four row groups through LDS; one atomic per element ----
+    // lds as [rg][tile][lane] float4; tiles of this half-wave pair: t = i * NBH + j  ->  (ua = i, ub = hb * NBH + j)
+    constexpr int NT = NA * NBH;                          // tiles per wave (<= 16)
+    float4 *red = reinterpret_cast<float4 *>(lds);        // 4 rg x 2 hb x NT x 64 float4 <= 128 KiB ... done in passes of TP tiles
+    constexpr int TP = NT < 4 ? NT : 4;                   // 8 waves x 4 tiles x 1 KiB = 32 KiB per pass
+#pragma unroll
+    for (int t0 = 0; t0 < NT; t0 += TP) {
+        __syncthreads();
+#pragma unroll
+        for (int tl = 0; tl < TP; ++tl) {
+            const int t = t0 + tl, i = t / NBH, j = t % NBH;
+            red[(wave * TP + tl) * 64 + lane] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        }
+        __syncthreads();
+        // 2 halves x TP tiles x 64 lanes float4 sums over the 4 row groups: 512 TP / 4 ... one per thread when TP == 4
+        for (int f = tid; f < 2 * TP * 64; f += TPB) {
+            const int ln = f & 63, tl = (f >> 6) % TP, h = (f >> 6) / TP;
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = red[((2 * q + h) * TP + tl) * 64 + ln];
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+            const int t = t0 + tl, ua = t / NBH, ub = h * NBH + t % NBH;
+            const int lc = ln & 15, lg = ln >> 4;
+            const int cbq = col_of<WB>(ub, lc);
+            const float sv[4] = { s.x, s.y, s.z, s.w };
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(DW + (size_t)col_of<WA>(ua, 4 * lg + r) * WB + cbq, sv[r]);
+        }
+    }
+    if (DB) {
+        // column sums of dz: over g inside the wave, then over the waves that hold them
+        constexpr int NZ = LAYOUT == 0 ? NA : NBH;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < NZ; ++u) {
+            float v = zsum[u];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (g == 0) {
+                const int col = LAYOUT == 0 ? col_of<O>(u, c) : col_of<O>(hb * NBH + u, c);
+                lds[wave * O + col] = v;                   // layout 0: only the hb == 0 waves summed; layout 1: each wave its half of the columns
+            }
+        }
+        __syncthreads();
+        if (tid < O) {
+            float s = 0.0f;
+            if constexpr (LAYOUT == 0) {
+#pragma unroll
+                for (int w = 0; w < NW; w += 2) s += lds[w * O + tid];
+            } else {
+                // column tid belongs to half h = tile / NBH of the permuted tiling
+                const int u = O == 32 ? (tid & 1) : 4 * (tid >> 6) + (tid & 3);
+                const int h = u / NBH;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) s += lds[(2 * q + h) * O + tid];
+            }
+            atomicAdd(DB + tid, s);
+        }
+    }
+}
+
+template <int KT, int OT, int ACT, int LAYOUT>
+static int launch(long R, const float *x, const float *w, const float *dy, const float *y, float *dx, float *dw, float *db, hipStream_t st) {
+    constexpr int K = 16 * KT, O = 16 * OT;
+    const size_t lds = ((size_t)2 * ROWS * (K + O) + (ACT ? (size_t)ROWS * O : 0)) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bwd_kernel<KT, OT, ACT, LAYOUT>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    static const int n_cu = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+    const long chunks = (R + ROWS - 1) / ROWS;
+    const int blocks = (int)std::min<long>(chunks, n_cu);
+    hipLaunchKernelGGL((bwd_kernel<KT, OT, ACT, LAYOUT>), dim3(blocks), dim3(TPB), std::max<size_t>(lds, 33 * 1024), st, R, x, w, dy, y, dx, dw, db);
+    CM_HIP(hipGetLastError());
+    return CM_OK;
+}
+
+}  // namespace lin2
+
+// Returns 1 when this shape / alignment is not covered (the caller runs lin::bwd_kernel), else the launch status.
+int linear_bwd_stream(long R, int K, int O, const float *x, const float *w, int layout, const float *dy, const float *y,
+                      float *dx, float *dw, float *db, void *stream) {
+    static const bool off = [] { const char *e = getenv("COMMARL_LIN_BWD"); return e && e[0] == 'o'; }();   // "old"
+    if (off) return 1;
+    const auto ok_w = [](int v) { return v == 32 || v == 64 || v == 128; };
+    if (!ok_w(K) || !ok_w(O) || (K == 128 && O == 128)) return 1;
+    const uintptr_t al = (uintptr_t)x | (uintptr_t)dy | (uintptr_t)y | (uintptr_t)dx;
+    if (al & 15) return 1;
+    if (layout == 1 && !(K == 64 && O == 64)) return 1;   // the [in][out] weights are the 64 x 64 graph-convolution ones
+    const hipStream_t st = (hipStream_t)stream;
+#define CM_B2(KT_, OT_, L_) (y ? lin2::launch<KT_, OT_, 1, L_>(R, x, w, dy, y, dx, dw, db, st) : lin2::launch<KT_, OT_, 0, L_>(R, x, w, dy, y, dx, dw, db, st))
+    if (layout == 1) return CM_B2(4, 4, 1);
+    switch (K * 1000 + O) {
+    case 32032: return CM_B2(2, 2, 0);
+    case 32064: return CM_B2(2, 4, 0);
+    case 32128: return CM_B2(2, 8, 0);
+    case 64032: return CM_B2(4, 2, 0);
+    case 64064: return CM_B2(4, 4, 0);
+    case 64128: return CM_B2(4, 8, 0);
+    case 128032: return CM_B2(8, 2, 0);
+    case 128064: return CM_B2(8, 4, 0);
+    default: return 1;
+    }
+#undef CM_B2
+}
+
+}  // namespace cm

@@ -433,6 +433,128 @@ __global__ __launch_bounds__(256) void multi_adam_kernel(TensorTable t, const fl
     if (norm_sq_next && blockIdx.x == 0 && threadIdx.x == 0) *norm_sq_next = 0.0f;     // the slot the NEXT step accumulates into
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// PPO clipped-surrogate loss + entropy bonus and its gradient wrt the logits, one launch (reference:
+// centralized_ma_ppo.py:390-438 _compute_loss, :540-589 _compute_objective; the Categorical(probs=...) arithmetic of
+// comm_categorical_mlp_policy.py:121-137: probs = softmax renormalised twice, logits = log(clamp(probs, eps, 1 - eps))).
+// One thread per env step: N agents x A <= 8 logits in registers; the chain rule is walked link by link (clamp ->
+// normalise -> normalise -> softmax) so that the result is the autograd one, term for term.
+//   total = - sum_{valid s} [ min(r adv, clamp(r, 1 - c, 1 + c) adv) + ent_coeff * mean_i H_i ],  r = exp(new_ll - old_ll)
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int PPO_MAX_A = 8;
+
+__global__ __launch_bounds__(256) void ppo_surrogate_kernel(int P, int T, int N, int A, const float *__restrict__ logits,
+                                                            const int32_t *__restrict__ actions, const float *__restrict__ old_ll,
+                                                            const float *__restrict__ adv, const int32_t *__restrict__ lens,
+                                                            float clip, float ent_coeff, int add_entropy,
+                                                            double *__restrict__ total, long long *__restrict__ count,
+                                                            float *__restrict__ dlogits) {
+    const long s = (long)blockIdx.x * 256 + threadIdx.x;
+    const long S = (long)P * T;
+    double part = 0.0;
+    int valid_here = 0;
+    if (s < S) {
+        const int pth = (int)(s / T), t = (int)(s - (long)pth * T);
+        const bool valid = t < lens[pth];
+        valid_here = valid ? 1 : 0;
+        const float EPS = 1.1920928955078125e-07f;            // torch.finfo(float32).eps: probs_to_logits clamps to [eps, 1 - eps]
+        const float *z0 = logits + s * N * A;
+        const int32_t *a0 = actions + s * N;
+        const float ol = old_ll[s], ad = adv[s];
+        // pass 1: new log-likelihood and entropy
+        float new_ll = 0.0f, ent = 0.0f;
+        for (int i = 0; i < N; ++i) {
+            float z[PPO_MAX_A], p[PPO_MAX_A];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int b = 0; b < PPO_MAX_A; ++b) if (b < A) { z[b] = z0[i * A + b]; mx = fmaxf(mx, z[b]); }
+            float s0 = 0.0f;
+#pragma unroll
+            for (int b = 0; b < PPO_MAX_A; ++b) if (b < A) { p[b] = expf(z[b] - mx); s0 += p[b]; }
+            float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+            for (int b = 0; b < PPO_MAX_A; ++b) if (b < A) { p[b] = p[b] / s0; s1 += p[b]; }
+#pragma unroll
+            for (int b = 0; b < PPO_MAX_A; ++b) if (b < A) { p[b] = p[b] / s1; s2 += p[b]; }
+            const int ai = a0[i];
+            float h = 0.0f;
+#pragma unroll
+            for (int b = 0; b < PPO_MAX_A; ++b) if (b < A) {
+                const float p3 = p[b] / s2;
+                const float lg = logf(fminf(fmaxf(p3, EPS), 1.0f - EPS));
+                h -= lg * p3;
+                if (b == ai) new_ll += lg;
+            }
+            ent += h;
+        }
+        ent /= (float)N;
+        const float r = expf(new_ll - ol);
+        const float rc = fminf(fmaxf(r, 1.0f - clip), 1.0f + clip);
+        const float sur = r * ad, clp = rc * ad;
+        float obj = fminf(sur, clp);
+        if (add_entropy) obj += ent_coeff * ent;
+        if (valid) part = -(double)obj;
+        if (dlogits) {
+            // d total / d new_ll: torch.min splits ties evenly; clamp passes the gradient inside [1 - c, 1 + c] (ends included)
+            const float wa = sur < clp ? 1.0f : (sur == clp ? 0.5f : 0.0f), wb = sur > clp ? 1.0f : (sur == clp ? 0.5f : 0.0f);
+            const float cg = (r >= 1.0f - clip && r <= 1.0f + clip) ? 1.0f : 0.0f;
+            const float g_ll = valid ? -(ad * wa + ad * cg * wb) * r : 0.0f;
+            const float g_h = (valid && add_entropy) ? -ent_coeff / (float)N : 0.0f;     // d total / d H_i
+            float *d0 = dlogits + s * N * A;
+            for (int i = 0; i < N; ++i) {
+                float z[PPO_MAX_A], p[PPO_MAX_A], p1[PPO_MAX_A], p2[PPO_MAX_A], p3[PPO_MAX_A], d[PPO_MAX_A];
+                float mx = -INFINITY;
+#pragma unroll
+                for (int b = 0; b < PPO_MAX_A; ++b) if (b < A) { z[b] = z0[i * A + b]; mx = fmaxf(mx, z[b]); }
+                float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+                for (int b = 0; b < PPO_MAX_A; ++b) if (b < A) { p[b] = expf(z[b] - mx); s0 += p[b]; }
+#pragma unroll
+                for (int b = 0; b < PPO_MAX_A; ++b) if (b < A) { p1[b] = p[b] / s0; s1 += p1[b]; }       // softmax
+#pragma unroll
+                for (int b = 0; b < PPO_MAX_A; ++b) if (b < A) { p2[b] = p1[b] / s1; s2 += p2[b]; }      // _probs: probs / probs.sum
+#pragma unroll
+                for (int b = 0; b < PPO_MAX_A; ++b) if (b < A) p3[b] = p2[b] / s2;                        // Categorical: again
+                const int ai = a0[i];
+                // d wrt p3: through logits = log(clamp(p3)) (log_prob gather + entropy's logits factor) and entropy's probs factor
+                float dot = 0.0f;
+#pragma unroll
+                for (int b = 0; b < PPO_MAX_A; ++b) if (b < A) {
+                    const float pc = fminf(fmaxf(p3[b], EPS), 1.0f - EPS);
+                    const float lg = logf(pc);
+                    const bool in = p3[b] >= EPS && p3[b] <= 1.0f - EPS;
+                    const float g_lg = (b == ai ? g_ll : 0.0f) - g_h * p3[b];       // H = - sum lg * p3
+                    d[b] = (in ? g_lg / pc : 0.0f) - g_h * lg;
+                    dot += d[b] * p3[b];
+                }
+#pragma unroll
+                for (int b = 0; b < PPO_MAX_A; ++b) if (b < A) d[b] = (d[b] - dot) / s2;                   // p3 = p2 / s2
+                dot = 0.0f;
+#pragma unroll
+                for (int b = 0; b < PPO_MAX_A; ++b) if (b < A) dot += d[b] * p2[b];
+#pragma unroll
+                for (int b = 0; b < PPO_MAX_A; ++b) if (b < A) d[b] = (d[b] - dot) / s1;                   // p2 = p1 / s1
+                dot = 0.0f;
+#pragma unroll
+                for (int b = 0; b < PPO_MAX_A; ++b) if (b < A) dot += d[b] * p1[b];
+#pragma unroll
+                for (int b = 0; b < PPO_MAX_A; ++b) if (b < A) d0[i * A + b] = p1[b] * (d[b] - dot);       // softmax
+            }
+        }
+    }
+    // block sums: f64 total, valid count
+    __shared__ double sh_t[4];
+    __shared__ int sh_c[4];
+    for (int o = 32; o > 0; o >>= 1) { part += __shfl_down(part, o); valid_here += __shfl_down(valid_here, o); }
+    if ((threadIdx.x & 63) == 0) { sh_t[threadIdx.x >> 6] = part; sh_c[threadIdx.x >> 6] = valid_here; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(total, sh_t[0] + sh_t[1] + sh_t[2] + sh_t[3]);
+        atomicAdd((unsigned long long *)count, (unsigned long long)(sh_c[0] + sh_c[1] + sh_c[2] + sh_c[3]));
+    }
+}
+
 }  // namespace cm
 
 using namespace cm;
@@ -571,6 +693,21 @@ extern "C" int cm_gae(int32_t P, int32_t T, const float *rewards, const float *b
     if (!rewards || !baselines || !adv) return set_error(CM_ERR_ARG, "cm_gae: null argument");
     if (P <= 0 || T <= 0) return CM_OK;
     hipLaunchKernelGGL(gae_kernel, dim3((P + 63) / 64), dim3(64), 0, (hipStream_t)stream, P, T, rewards, baselines, lens, gamma, lam, normalize, eps, adv);
+    CM_HIP(hipGetLastError());
+    return CM_OK;
+}
+
+extern "C" int cm_ppo_surrogate(int32_t P, int32_t T, int32_t N, int32_t A, const float *logits, const int32_t *actions,
+                                const float *old_ll, const float *adv, const int32_t *lens, float clip, float ent_coeff,
+                                int32_t add_entropy, double *total, int64_t *count, float *dlogits, void *stream) {
+    if (!logits || !actions || !old_ll || !adv || !lens || !total || !count) return set_error(CM_ERR_ARG, "cm_ppo_surrogate: null argument");
+    if (A < 1 || A > PPO_MAX_A || N < 1) return set_error(CM_ERR_ARG, "cm_ppo_surrogate: 1 <= n_actions <= 8 and n_agents >= 1 required");
+    if (P <= 0 || T <= 0) return CM_OK;
+    CM_HIP(hipMemsetAsync(total, 0, sizeof(double), (hipStream_t)stream));
+    CM_HIP(hipMemsetAsync(count, 0, sizeof(int64_t), (hipStream_t)stream));
+    const long S = (long)P * T;
+    hipLaunchKernelGGL(ppo_surrogate_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P, T, N, A, logits, actions,
+                       old_ll, adv, lens, clip, ent_coeff, add_entropy, total, (long long *)count, dlogits);
     CM_HIP(hipGetLastError());
     return CM_OK;
 }

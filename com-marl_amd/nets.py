@@ -409,6 +409,29 @@ class _FusedNetFn(torch.autograd.Function):
         return (None, None, None, None) + tuple(g.get(n) for n in ctx.names)
 
 
+@torch.no_grad()
+def _fused_logits_nograd(net, obs, adj, ch):
+    """Policy logits [S,N,A] + attention from the saved-forward kernel with every store but the logits switched off
+    (loss evaluations over the full batch: no activations kept)."""
+    N, d, A = net._n_agents, net._dec_obs_dim, net._action_dim
+    S = obs.shape[0]
+    obs2 = obs.reshape(S * N, d).contiguous()
+    out = torch.empty(S * N, A, dtype=torch.float32, device=obs.device)
+    attn = torch.empty(S, N, N, dtype=torch.float32, device=obs.device)
+    sv = L.FwdSaves()
+    sv.out = out.data_ptr()
+    adj_c = None if adj is None else adj.contiguous()
+    ch_c = None if ch is None else ch.contiguous()
+    with torch.cuda.device(obs.device):
+        w = net._weights_struct()
+        rc = L.lib().cm_policy_forward_saved(C.byref(w), S, L.ptr(obs2), L.ptr(adj_c), L.ptr(ch_c), L.ptr(attn), C.byref(sv),
+                                             L.current_stream())
+    if rc == 1:
+        raise L.CommarlError("no saved-forward instantiation for this shape")
+    L.check(rc, "cm_policy_forward_saved")
+    return out.view(S, N, A), attn
+
+
 # ---------------------------------------------------------------------------------------------
 # trunk
 # ---------------------------------------------------------------------------------------------
@@ -587,14 +610,29 @@ class CommCategoricalMLPPolicy(CommBaseNet):
         self.to(device)
 
     # -- autograd path (PPO update) --------------------------------------------------------------
+    def _logits_flat(self, obs, adj, ch):
+        """Raw head outputs [S,N,A] and attention [S,N,N] of flattened inputs: the fused training forward when it has an
+        instantiation, under no_grad the same kernel storing only the logits, else the per-layer path."""
+        fused_shape = len(self.categorical_output_layer._layers) == 3
+        if _fused_train_ok(self, obs) and fused_shape:
+            return _FusedNetFn.apply(self, obs, adj, ch, *self.parameters())          # one forward launch + hand-written backward
+        if not torch.is_grad_enabled() and fused_shape:
+            with torch.enable_grad():
+                ok = _fused_train_ok(self, obs)
+            if ok:
+                return _fused_logits_nograd(self, obs, adj, ch)
+        E, H, M = self.trunk(obs, adj, ch)
+        x = E + H if self.residual else H
+        return self.categorical_output_layer(x), M
+
+    def _logits(self, obs_n, dist_adj, channels):
+        lead, S, obs, adj, ch = self._flatten(obs_n, dist_adj, channels)
+        logits, _ = self._logits_flat(obs, adj, ch)
+        return logits.reshape(*lead, self._n_agents, -1)
+
     def _probs(self, obs_n, avail_actions_n, dist_adj, channels):
         lead, S, obs, adj, ch = self._flatten(obs_n, dist_adj, channels)
-        if _fused_train_ok(self, obs) and len(self.categorical_output_layer._layers) == 3:
-            logits, M = _FusedNetFn.apply(self, obs, adj, ch, *self.parameters())     # one forward launch + hand-written backward
-        else:
-            E, H, M = self.trunk(obs, adj, ch)
-            x = E + H if self.residual else H
-            logits = self.categorical_output_layer(x)
+        logits, M = self._logits_flat(obs, adj, ch)
         probs = torch.softmax(logits, dim=-1)
         if avail_actions_n is not None:
             probs = probs * avail_actions_n.reshape(S, self._n_agents, -1)

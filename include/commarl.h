@@ -355,6 +355,16 @@ int cm_discount_returns(int32_t P, int32_t T, const double *rewards, const int32
 int cm_gae(int32_t P, int32_t T, const float *rewards, const float *baselines, const int32_t *lens, float gamma,
            float lam, int32_t normalize, float eps, float *adv, void *stream);
 
+/* PPO clipped-surrogate loss with entropy bonus over a padded [P,T] batch and its gradient wrt the policy logits
+ * [P*T,N,A] (centralized_ma_ppo.py:390-438 _compute_loss, :540-589 _compute_objective; Categorical(probs=...) as built by
+ * comm_categorical_mlp_policy.py:48-96, entropy / log_prob :121-137):
+ *   *total = - sum over valid steps of [ min(r adv, clamp(r, 1 - clip, 1 + clip) adv) + ent_coeff * mean_i H_i ]   (f64)
+ *   *count = number of valid steps (t < lens[p]);  dlogits (nullable) = d total / d logits, zero on padded steps.
+ * add_entropy = 0 drops the entropy term (entropy_method != "regularized"). */
+int cm_ppo_surrogate(int32_t P, int32_t T, int32_t N, int32_t A, const float *logits, const int32_t *actions,
+                     const float *old_ll, const float *adv, const int32_t *lens, float clip, float ent_coeff,
+                     int32_t add_entropy, double *total, int64_t *count, float *dlogits, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -4,7 +4,7 @@ import os, sys
 sys.path.insert(0, '.')
 import torch
 from com_marl_amd import _lib as L
-R = int(os.environ.get("ROWS", 1098240))
+R = int(os.environ.get("ROWS", 548000))
 dev = "cuda:0"
 def t(fn, n=10):
     for _ in range(3): fn()
@@ -16,7 +16,7 @@ def t(fn, n=10):
     return e0.elapsed_time(e1) / n * 1e3
 lib = L.lib()
 st = lambda: torch.cuda.current_stream().cuda_stream
-for K, O in ((128, 64), (64, 128), (64, 64), (21, 128), (64, 32)):
+for K, O in ((128, 64), (64, 128), (64, 64), (21, 128), (64, 32), (32, 128)):
     x = torch.randn(R, K, device=dev); w = torch.randn(O, K, device=dev) * 0.1; b = torch.zeros(O, device=dev)
     y = torch.empty(R, O, device=dev); dy = torch.randn(R, O, device=dev); dx = torch.empty(R, K, device=dev)
     dw = torch.zeros(O, K, device=dev); db = torch.zeros(O, device=dev)
