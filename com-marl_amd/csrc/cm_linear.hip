@@ -43,7 +43,7 @@ __device__ __forceinline__ float w_at(const float *__restrict__ W, int layout, i
 // (the observation, the 5 logits, the critic's scalar) are small and go four loads at a time.
 template <bool DZ>
 __device__ __forceinline__ void stage(float *dst, int stride, const float *__restrict__ src, const float *__restrict__ yv, int W,
-                                      long r0, int rows, int tid) {
+                                      long r0, int rows, int tid, const float *__restrict__ src2 = nullptr) {
     const int w4 = W >> 2;
     if ((W & 3) == 0 && (w4 & (w4 - 1)) == 0 && w4 >= 4 && w4 <= 32) {
         const int x = tid & (w4 - 1), rstep = TPB / w4, rb = tid / w4, ni = ROWS / rstep;      // ni = w4 / 4 <= 8
@@ -55,6 +55,7 @@ __device__ __forceinline__ void stage(float *dst, int stride, const float *__res
             const int r = rb + i * rstep;
             if (i < ni && r < rows) {
                 q[i] = reinterpret_cast<const float4 *>(src + (r0 + r) * W)[x];
+                if (src2) { const float4 u = reinterpret_cast<const float4 *>(src2 + (r0 + r) * W)[x]; q[i].x += u.x; q[i].y += u.y; q[i].z += u.z; q[i].w += u.w; }
                 if (DZ) y[i] = reinterpret_cast<const float4 *>(yv + (r0 + r) * W)[x];
             }
         }
@@ -75,7 +76,7 @@ __device__ __forceinline__ void stage(float *dst, int stride, const float *__res
                 const int k = k0 + u * TPB, r = k / W, x = k - r * W;
                 off[u] = k < ROWS * W ? r * stride + x : -1;
                 v[u] = 0.0f; yy[u] = 0.0f;
-                if (k < ROWS * W && r < rows) { v[u] = src[(r0 + r) * W + x]; if (DZ) yy[u] = yv[(r0 + r) * W + x]; }
+                if (k < ROWS * W && r < rows) { v[u] = src[(r0 + r) * W + x]; if (src2) v[u] += src2[(r0 + r) * W + x]; if (DZ) yy[u] = yv[(r0 + r) * W + x]; }
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
@@ -160,7 +161,8 @@ __global__ __launch_bounds__(TPB) void fwd_kernel(long R, int K, int O, const fl
 // ---------------------------------------------------------------------------------------------------------------
 template <int MAXT, int ACT>
 __global__ __launch_bounds__(TPB, (MAXT == 8 ? 2 : 1)) void bwd_kernel(long R, int K, int O, const float *__restrict__ X, const float *__restrict__ W,
-                                                 int layout, const float *__restrict__ DY, const float *__restrict__ Yv,
+                                                 int layout, const float *__restrict__ DY, const float *__restrict__ DY2,
+                                                 const float *__restrict__ Yv,
                                                  float *__restrict__ DX, float *__restrict__ DW, float *__restrict__ DB) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(TPB, (MAXT == 8 ? 2 : 1)) void bwd_kernel(long R, i
     for (long ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
         const long r0 = ch * ROWS;
         const int rows = (int)min((long)ROWS, R - r0);
-        stage<ACT != 0>(Zs, SZ, DY, Yv, O, r0, rows, tid);
+        stage<ACT != 0>(Zs, SZ, DY, Yv, O, r0, rows, tid, DY2);
         stage<false>(Xs, SXs, X, nullptr, K, r0, rows, tid);
         __syncthreads();
         if (DB && tid < O) { float s = 0.0f; for (int r = 0; r < ROWS; ++r) s += Zs[(size_t)r * SZ + tid]; csum += s; }
@@ -278,8 +280,8 @@ __global__ __launch_bounds__(TPB, (MAXT == 8 ? 2 : 1)) void bwd_kernel(long R, i
 }  // namespace cm
 
 namespace cm {
-int linear_bwd_stream(long R, int K, int O, const float *x, const float *w, int layout, const float *dy, const float *y,
-                      float *dx, float *dw, float *db, void *stream);   // cm_linear_bwd.hip: widths 32 / 64 / 128
+int linear_bwd_stream(long R, int K, int O, const float *x, const float *w, int layout, const float *dy, const float *dy2,
+                      const float *y, float *dx, float *dw, float *db, void *stream);   // cm_linear_bwd.hip: widths 32 / 64 / 128
 }
 using namespace cm;
 
@@ -300,12 +302,13 @@ extern "C" int cm_linear_act_forward(int64_t R, int32_t K, int32_t O, const floa
 }
 
 extern "C" int cm_linear_act_backward(int64_t R, int32_t K, int32_t O, const float *x, const float *w, int32_t w_layout,
-                                      const float *dy, const float *y, float *dx, float *dw, float *db, void *stream) {
+                                      const float *dy, const float *dy2, const float *y, float *dx, float *dw, float *db,
+                                      void *stream) {
     if (!x || !w || !dy || !dw) return set_error(CM_ERR_ARG, "cm_linear_act_backward: null argument");
     if (K < 1 || O < 1 || K > 128 || O > 128) return set_error(CM_ERR_ARG, "cm_linear_act_backward: 1 <= in, out <= 128 required");
     if (w_layout != 0 && w_layout != 1) return set_error(CM_ERR_ARG, "cm_linear_act_backward: w_layout must be 0 ([out,in]) or 1 ([in,out])");
     if (R <= 0) return CM_OK;
-    if (const int rc = linear_bwd_stream(R, K, O, x, w, w_layout, dy, y, dx, dw, db, stream); rc != 1) return rc;
+    if (const int rc = linear_bwd_stream(R, K, O, x, w, w_layout, dy, dy2, y, dx, dw, db, stream); rc != 1) return rc;
     const int OT = (O + 15) / 16, KT = (K + 15) / 16, NT = OT * KT;
     const size_t lds = ((size_t)lin::ROWS * (OT * 16 + 16) + (size_t)lin::ROWS * (KT * 16 + 16)) * sizeof(float);
     const long chunks = (R + lin::ROWS - 1) / lin::ROWS;
@@ -320,8 +323,8 @@ extern "C" int cm_linear_act_backward(int64_t R, int32_t K, int32_t O, const flo
 #undef CM_ATTR
         once = true;
     }
-#define CM_LB(M) do { if (y) hipLaunchKernelGGL((lin::bwd_kernel<M, 1>), dim3(blocks), dim3(lin::TPB), lds, st, (long)R, K, O, x, w, w_layout, dy, y, dx, dw, db); \
-                      else hipLaunchKernelGGL((lin::bwd_kernel<M, 0>), dim3(blocks), dim3(lin::TPB), lds, st, (long)R, K, O, x, w, w_layout, dy, y, dx, dw, db); } while (0)
+#define CM_LB(M) do { if (y) hipLaunchKernelGGL((lin::bwd_kernel<M, 1>), dim3(blocks), dim3(lin::TPB), lds, st, (long)R, K, O, x, w, w_layout, dy, dy2, y, dx, dw, db); \
+                      else hipLaunchKernelGGL((lin::bwd_kernel<M, 0>), dim3(blocks), dim3(lin::TPB), lds, st, (long)R, K, O, x, w, w_layout, dy, dy2, y, dx, dw, db); } while (0)
     if (per_wave <= 1) CM_LB(1); else if (per_wave <= 2) CM_LB(2); else if (per_wave <= 4) CM_LB(4);
     else if (per_wave <= 8) CM_LB(8); else CM_LB(16);
 #undef CM_LB

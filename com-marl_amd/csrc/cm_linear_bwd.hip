@@ -1,6 +1,6 @@
 // cm_linear_bwd.hip - streaming backward of one dense layer for widths 32 / 64 / 128 (every hidden layer of the nets):
 //
-//   dz = dy * act'(y);  dx = dz.W;  dW += dz^T.x (or x^T.dz);  db += colsum(dz)      reads dy, y, x once; writes dx once
+//   dz = (dy + dy2) * act'(y);  dx = dz.W;  dW += dz^T.x (or x^T.dz);  db += colsum(dz)      reads dy, y, x once; writes dx once
 //
 // (reference: the autograd of nn.Linear + tanh in garage/torch/modules/multi_headed_mlp_module.py:134-149,
 // GraphConvolutionModule's H.W graph_conv_module.py:63, AttentionModule.linear_in attention_module.py:36.)
@@ -93,7 +93,8 @@ __device__ __forceinline__ void load_cols(const float *tile, int r, int c, int u
 
 template <int KT, int OT, int ACT, int LAYOUT>
 __global__ __launch_bounds__(TPB) void bwd_kernel(long R, const float *__restrict__ X, const float *__restrict__ W,
-                                                  const float *__restrict__ DY, const float *__restrict__ Yv,
+                                                  const float *__restrict__ DY, const float *__restrict__ DY2,
+                                                  const float *__restrict__ Yv,
                                                   float *__restrict__ DX, float *__restrict__ DW, float *__restrict__ DB) {
     constexpr int K = 16 * KT, O = 16 * OT;
     constexpr int ZF = ROWS * O, XF = ROWS * K, BUF = ZF + XF;
@@ -101,7 +102,8 @@ __global__ __launch_bounds__(TPB) void bwd_kernel(long R, const float *__restric
     constexpr int NA = WA / 16, NBH = WB / 32;                          // A tiles; B tiles of this wave's half
     constexpr int NKT = KT / 2;                                         // dx column tiles per wave
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *Ys = lds + 2 * BUF;
+    float *Ys = lds + 2 * BUF;                            // y tile (ACT) and, behind it, the second gradient's tile (DY2)
+    float *D2s = Ys + (ACT ? ZF : 0);
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)lds;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
     const int rg = wave >> 1, hb = wave & 1;
@@ -135,13 +137,19 @@ __global__ __launch_bounds__(TPB) void bwd_kernel(long R, const float *__restric
     // dz = dy * (1 - y^2) in place, and zero rows past the end of the last chunk (the DMA re-read a valid row there)
     auto finish_tile = [&](float *buf, int rows) {
         float *Zs = buf, *Xs = buf + ZF;
-        if (ACT) {
+        if (ACT || DY2) {
 #pragma unroll
             for (int i = 0; i < ZF / (4 * TPB); ++i) {
                 const int p = 4 * (tid + i * TPB);
                 float4 z = *reinterpret_cast<float4 *>(Zs + p);
-                const float4 y = *reinterpret_cast<const float4 *>(Ys + p);
-                z.x *= 1.0f - y.x * y.x; z.y *= 1.0f - y.y * y.y; z.z *= 1.0f - y.z * y.z; z.w *= 1.0f - y.w * y.w;
+                if (DY2) {
+                    const float4 u = *reinterpret_cast<const float4 *>(D2s + p);
+                    z.x += u.x; z.y += u.y; z.z += u.z; z.w += u.w;
+                }
+                if (ACT) {
+                    const float4 y = *reinterpret_cast<const float4 *>(Ys + p);
+                    z.x *= 1.0f - y.x * y.x; z.y *= 1.0f - y.y * y.y; z.z *= 1.0f - y.z * y.z; z.w *= 1.0f - y.w * y.w;
+                }
                 if (p >= rows * O) z = make_float4(0.f, 0.f, 0.f, 0.f);
                 *reinterpret_cast<float4 *>(Zs + p) = z;
             }
@@ -158,6 +166,7 @@ __global__ __launch_bounds__(TPB) void bwd_kernel(long R, const float *__restric
         issue_tile<O>(b, DY, r0, rows, wave, lane);
         issue_tile<K>(b + ZF * (unsigned)sizeof(float), X, r0, rows, wave, lane);
         if (ACT) issue_tile<O>(lds_base + 2 * BUF * (unsigned)sizeof(float), Yv, r0, rows, wave, lane);
+        if (DY2) issue_tile<O>(lds_base + (2 * BUF + (ACT ? ZF : 0)) * (unsigned)sizeof(float), DY2, r0, rows, wave, lane);
     };
     if (ch < n_chunks) {
         issue(lds, ch);
@@ -226,7 +235,7 @@ __global__ __launch_bounds__(TPB) void bwd_kernel(long R, const float *__restric
         __syncthreads();                                   // chunk `next` has landed; every wave is done with `cur`
         if (next < n_chunks) {
             const int nrows = (int)min((long)ROWS, R - next * ROWS);
-            if (ACT || nrows < ROWS) {
+            if (ACT || DY2 || nrows < ROWS) {
                 finish_tile(nxt, nrows);
                 __syncthreads();
             }
@@ -297,9 +306,11 @@ __global__ __launch_bounds__(TPB) void bwd_kernel(long R, const float *__restric
 }
 
 template <int KT, int OT, int ACT, int LAYOUT>
-static int launch(long R, const float *x, const float *w, const float *dy, const float *y, float *dx, float *dw, float *db, hipStream_t st) {
+static int launch(long R, const float *x, const float *w, const float *dy, const float *dy2, const float *y, float *dx, float *dw, float *db,
+                  hipStream_t st) {
     constexpr int K = 16 * KT, O = 16 * OT;
-    const size_t lds = ((size_t)2 * ROWS * (K + O) + (ACT ? (size_t)ROWS * O : 0)) * sizeof(float);
+    const size_t lds = ((size_t)2 * ROWS * (K + O) + (ACT ? (size_t)ROWS * O : 0) + (dy2 ? (size_t)ROWS * O : 0)) * sizeof(float);
+    if (lds > 160 * 1024) return 1;
     static bool attr = false;
     if (!attr) {
         CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bwd_kernel<KT, OT, ACT, LAYOUT>),
@@ -309,7 +320,7 @@ static int launch(long R, const float *x, const float *w, const float *dy, const
     static const int n_cu = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
     const long chunks = (R + ROWS - 1) / ROWS;
     const int blocks = (int)std::min<long>(chunks, n_cu);
-    hipLaunchKernelGGL((bwd_kernel<KT, OT, ACT, LAYOUT>), dim3(blocks), dim3(TPB), std::max<size_t>(lds, 33 * 1024), st, R, x, w, dy, y, dx, dw, db);
+    hipLaunchKernelGGL((bwd_kernel<KT, OT, ACT, LAYOUT>), dim3(blocks), dim3(TPB), std::max<size_t>(lds, 33 * 1024), st, R, x, w, dy, dy2, y, dx, dw, db);
     CM_HIP(hipGetLastError());
     return CM_OK;
 }
@@ -317,17 +328,17 @@ static int launch(long R, const float *x, const float *w, const float *dy, const
 }  // namespace lin2
 
 // Returns 1 when this shape / alignment is not covered (the caller runs lin::bwd_kernel), else the launch status.
-int linear_bwd_stream(long R, int K, int O, const float *x, const float *w, int layout, const float *dy, const float *y,
-                      float *dx, float *dw, float *db, void *stream) {
+int linear_bwd_stream(long R, int K, int O, const float *x, const float *w, int layout, const float *dy, const float *dy2,
+                      const float *y, float *dx, float *dw, float *db, void *stream) {
     static const bool off = [] { const char *e = getenv("COMMARL_LIN_BWD"); return e && e[0] == 'o'; }();   // "old"
     if (off) return 1;
     const auto ok_w = [](int v) { return v == 32 || v == 64 || v == 128; };
     if (!ok_w(K) || !ok_w(O) || (K == 128 && O == 128)) return 1;
-    const uintptr_t al = (uintptr_t)x | (uintptr_t)dy | (uintptr_t)y | (uintptr_t)dx;
+    const uintptr_t al = (uintptr_t)x | (uintptr_t)dy | (uintptr_t)dy2 | (uintptr_t)y | (uintptr_t)dx;
     if (al & 15) return 1;
     if (layout == 1 && !(K == 64 && O == 64)) return 1;   // the [in][out] weights are the 64 x 64 graph-convolution ones
     const hipStream_t st = (hipStream_t)stream;
-#define CM_B2(KT_, OT_, L_) (y ? lin2::launch<KT_, OT_, 1, L_>(R, x, w, dy, y, dx, dw, db, st) : lin2::launch<KT_, OT_, 0, L_>(R, x, w, dy, y, dx, dw, db, st))
+#define CM_B2(KT_, OT_, L_) (y ? lin2::launch<KT_, OT_, 1, L_>(R, x, w, dy, dy2, y, dx, dw, db, st) : lin2::launch<KT_, OT_, 0, L_>(R, x, w, dy, dy2, y, dx, dw, db, st))
     if (layout == 1) return CM_B2(4, 4, 1);
     switch (K * 1000 + O) {
     case 32032: return CM_B2(2, 2, 0);

@@ -73,7 +73,8 @@ template <int E>
 __global__ __launch_bounds__(TPB) void agg_bwd_kernel(int S, int N, int EPB, const float *__restrict__ attn,
                                                      const float *__restrict__ adj, const float *__restrict__ chan,
                                                      long ch_stride, const float *__restrict__ hw,
-                                                     const float *__restrict__ outv, const float *__restrict__ d_out,
+                                                     const float *__restrict__ outv, const float *__restrict__ out_minus,
+                                                     const float *__restrict__ d_out,
                                                      float *__restrict__ d_attn, float *__restrict__ d_hw,
                                                      float *__restrict__ d_bias) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(TPB) void agg_bwd_kernel(int S, int N, int EPB, con
             const int r = k / E, c = k - r * E;
             const size_t g = (size_t)s0 * N * E + k;
             HW[(size_t)r * SE + c] = hw[g];
-            const float y = outv[g];
+            const float y = out_minus ? outv[g] - out_minus[g] : outv[g];
             const float dp = d_out[g] * (1.0f - y * y);          // tanh'
             DP[(size_t)r * SE + c] = dp;
         }
@@ -222,7 +223,8 @@ __global__ __launch_bounds__(TPB) void attn_fwd_kernel(int S, int N, int EPB, co
 template <int E>
 __global__ __launch_bounds__(TPB) void attn_bwd_kernel(int S, int N, int EPB, const float *__restrict__ q,
                                                       const float *__restrict__ e, const float *__restrict__ m,
-                                                      const float *__restrict__ d_m, float *__restrict__ d_q,
+                                                      const float *__restrict__ d_m, const float *__restrict__ add0,
+                                                      const float *__restrict__ add1, float *__restrict__ d_q,
                                                       float *__restrict__ d_e) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int SE = E + 4;
@@ -260,8 +262,12 @@ __global__ __launch_bounds__(TPB) void attn_bwd_kernel(int S, int N, int EPB, co
 #pragma unroll
             for (int i = 0; i < RC; ++i)
                 if (r0 + i < rows && (r0 + i) / N == en) {
-                    d_q[((size_t)s0 * N + r0 + i) * E + o] = aq[i];
-                    d_e[((size_t)s0 * N + r0 + i) * E + o] = ae[i];
+                    const size_t at = ((size_t)s0 * N + r0 + i) * E + o;
+                    d_q[at] = aq[i];
+                    float v = ae[i];
+                    if (add0) v += add0[at];
+                    if (add1) v += add1[at];
+                    d_e[at] = v;
                 }
         }
         __syncthreads();
@@ -602,7 +608,7 @@ extern "C" int cm_masked_agg_forward(int32_t S, int32_t N, int32_t E, const floa
 }
 
 extern "C" int cm_masked_agg_backward(int32_t S, int32_t N, int32_t E, const float *attn, const float *dist_adj,
-                                      const float *chan, int64_t ch_stride, const float *hw, const float *out,
+                                      const float *chan, int64_t ch_stride, const float *hw, const float *out, const float *out_minus,
                                       const float *d_out, float *d_attn, float *d_hw, float *d_bias, void *stream) {
     if (!attn || !hw || !out || !d_out || !d_attn || !d_hw) return set_error(CM_ERR_ARG, "cm_masked_agg_backward: null argument");
     if (E != 64) return set_error(CM_ERR_ARG, "cm_masked_agg_backward: embedding dim 64 only");
@@ -613,7 +619,7 @@ extern "C" int cm_masked_agg_backward(int32_t S, int32_t N, int32_t E, const flo
     if (!once) { CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_bwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
     const int epb = agg_epb(N);
     const int blocks = (int)std::min<long>((S + epb - 1) / epb, 256 * 4);
-    hipLaunchKernelGGL(agg_bwd_kernel<64>, dim3(blocks), dim3(TPB), lds, (hipStream_t)stream, S, N, epb, attn, dist_adj, chan, (long)ch_stride, hw, out, d_out, d_attn, d_hw, d_bias);
+    hipLaunchKernelGGL(agg_bwd_kernel<64>, dim3(blocks), dim3(TPB), lds, (hipStream_t)stream, S, N, epb, attn, dist_adj, chan, (long)ch_stride, hw, out, out_minus, d_out, d_attn, d_hw, d_bias);
     CM_HIP(hipGetLastError());
     return CM_OK;
 }
@@ -664,8 +670,10 @@ extern "C" int cm_attention_forward(int32_t S, int32_t N, int32_t E, const float
 }
 
 extern "C" int cm_attention_backward(int32_t S, int32_t N, int32_t E, const float *q, const float *e, const float *m,
-                                     const float *d_m, float *d_q, float *d_e, void *stream) {
+                                     const float *d_m, const float *d_e_add0, const float *d_e_add1, float *d_q, float *d_e,
+                                     void *stream) {
     if (!q || !e || !m || !d_m || !d_q || !d_e) return set_error(CM_ERR_ARG, "cm_attention_backward: null argument");
+    if (d_e == d_e_add0 || d_e == d_e_add1) return set_error(CM_ERR_ARG, "cm_attention_backward: d_e must not alias its addends");
     if (E != 64) return set_error(CM_ERR_ARG, "cm_attention_backward: embedding dim 64 only");
     if (S <= 0) return CM_OK;
     const size_t lds = attn_lds(N, E);
@@ -674,7 +682,7 @@ extern "C" int cm_attention_backward(int32_t S, int32_t N, int32_t E, const floa
     if (!once) { CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_bwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
     const int epb = agg_epb(N);
     const int blocks = (int)std::min<long>((S + epb - 1) / epb, 256 * 8);
-    hipLaunchKernelGGL(attn_bwd_kernel<64>, dim3(blocks), dim3(TPB), lds, (hipStream_t)stream, S, N, epb, q, e, m, d_m, d_q, d_e);
+    hipLaunchKernelGGL(attn_bwd_kernel<64>, dim3(blocks), dim3(TPB), lds, (hipStream_t)stream, S, N, epb, q, e, m, d_m, d_e_add0, d_e_add1, d_q, d_e);
     CM_HIP(hipGetLastError());
     return CM_OK;
 }

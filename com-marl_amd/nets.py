@@ -84,7 +84,7 @@ class _AttentionSoftmax(torch.autograd.Function):
         d_m = d_m.contiguous()
         d_q, d_e = torch.empty_like(q), torch.empty_like(e)
         with torch.cuda.device(e.device):
-            L.check(L.lib().cm_attention_backward(S, N, E, L.ptr(q), L.ptr(e), L.ptr(m), L.ptr(d_m), L.ptr(d_q),
+            L.check(L.lib().cm_attention_backward(S, N, E, L.ptr(q), L.ptr(e), L.ptr(m), L.ptr(d_m), None, None, L.ptr(d_q),
                                                   L.ptr(d_e), L.current_stream()), "cm_attention_backward")
         return d_q, d_e
 
@@ -199,7 +199,7 @@ class _LinearActFn(torch.autograd.Function):
         dw = torch.zeros_like(w)
         db = torch.zeros(O, dtype=torch.float32, device=w.device) if has_bias else None
         with torch.cuda.device(w.device):
-            L.check(L.lib().cm_linear_act_backward(x2.shape[0], K, O, L.ptr(x2), L.ptr(w), layout, L.ptr(dy2), L.ptr(y),
+            L.check(L.lib().cm_linear_act_backward(x2.shape[0], K, O, L.ptr(x2), L.ptr(w), layout, L.ptr(dy2), None, L.ptr(y),
                                                    L.ptr(dx), L.ptr(dw), L.ptr(db), L.current_stream()),
                     "cm_linear_act_backward")
         return (None if dx is None else dx.reshape(shape)), dw, db, None, None
@@ -260,7 +260,7 @@ class _MaskedAggregate(torch.autograd.Function):
             chan_ptr, stride = chan_all.data_ptr() + 4 * ctx.hop * N * N, chan_all.shape[1] * N * N
         with torch.cuda.device(hw.device):
             L.check(L.lib().cm_masked_agg_backward(S, N, E, L.ptr(attn), L.ptr(dist_adj), chan_ptr, stride, L.ptr(hw),
-                                                   L.ptr(out), L.ptr(d_out), L.ptr(d_attn), L.ptr(d_hw),
+                                                   L.ptr(out), None, L.ptr(d_out), L.ptr(d_attn), L.ptr(d_hw),
                                                    L.ptr(d_bias), L.current_stream()), "cm_masked_agg_backward")
         return d_attn, None, None, None, d_hw, d_bias
 
@@ -276,16 +276,17 @@ def masked_aggregate(attn, dist_adj, channels, hop, hw, bias):
 # whole-network training forward (teams of 4): ONE fused launch that stores what the backward needs, and a hand-written
 # backward chain over the C-ABI kernels - no per-layer forward kernels, no gradient-accumulation adds from autograd
 # ---------------------------------------------------------------------------------------------
-def _lin_bwd(x2, w, layout, dy2, y2, want_dx, has_bias):
-    """cm_linear_act_backward on 2-D contiguous tensors -> (dx | None, dw, db | None)."""
+def _lin_bwd(x2, w, layout, dy2, y2, want_dx, has_bias, dy_add=None):
+    """cm_linear_act_backward on 2-D contiguous tensors -> (dx | None, dw, db | None); dy_add: a second gradient into the
+    layer's output, summed inside the kernel."""
     R, K = x2.shape
     O = dy2.shape[1]
     dx = torch.empty_like(x2) if want_dx else None
     dw = torch.zeros_like(w)
     db = torch.zeros(O, dtype=torch.float32, device=w.device) if has_bias else None
     with torch.cuda.device(w.device):
-        L.check(L.lib().cm_linear_act_backward(R, K, O, L.ptr(x2), L.ptr(w), layout, L.ptr(dy2), L.ptr(y2), L.ptr(dx), L.ptr(dw),
-                                               L.ptr(db), L.current_stream()), "cm_linear_act_backward")
+        L.check(L.lib().cm_linear_act_backward(R, K, O, L.ptr(x2), L.ptr(w), layout, L.ptr(dy2), L.ptr(dy_add), L.ptr(y2), L.ptr(dx),
+                                               L.ptr(dw), L.ptr(db), L.current_stream()), "cm_linear_act_backward")
     return dx, dw, db
 
 
@@ -373,19 +374,19 @@ class _FusedNetFn(torch.autograd.Function):
             d, g[pre + "_layers.0.linear.weight"], g[pre + "_layers.0.linear.bias"] = _lin_bwd(t["h"][Lh - 1], l1.weight, 0, d, t["x1"], True, True)
         # d = gradient wrt the trunk output x = E + H_L (or H_L)
         e, q = t["e"], t["q"]
-        dE = d if net.residual else None                                 # residual: the same gradient flows into E
-        dH, d_attn = d, None
+        d_res = d if net.residual else None                              # residual: the same gradient flows into E
+        dH, d_attn, dhin0 = d, None, None
         with torch.cuda.device(obs2.device):
             for l in reversed(range(Lh)):
                 gl = net.gcn_layers[l]
-                out_l = (t["h"][l] - e) if (l == Lh - 1 and net.residual) else t["h"][l]      # tanh output of hop l
+                minus = e if (l == Lh - 1 and net.residual) else None       # saved x = E + H_L: the hop's tanh output is x - E
                 da, dhw = torch.empty_like(attn), torch.empty_like(e)
                 dgb = torch.zeros(64, dtype=torch.float32, device=e.device) if gl.bias is not None else None
                 chan_ptr, stride = None, 0
                 if ch is not None:
                     chan_ptr, stride = ch.data_ptr() + 4 * l * N * N, ch.shape[1] * N * N
                 L.check(L.lib().cm_masked_agg_backward(S, N, 64, L.ptr(attn), L.ptr(adj), chan_ptr, stride, L.ptr(t["hw"][l]),
-                                                       L.ptr(out_l), L.ptr(dH), L.ptr(da), L.ptr(dhw), L.ptr(dgb),
+                                                       L.ptr(t["h"][l]), L.ptr(minus), L.ptr(dH), L.ptr(da), L.ptr(dhw), L.ptr(dgb),
                                                        L.current_stream()), "cm_masked_agg_backward")
                 d_attn = da if d_attn is None else d_attn.add_(da)
                 hin = t["h"][l - 1] if l > 0 else e
@@ -395,15 +396,18 @@ class _FusedNetFn(torch.autograd.Function):
                 if l > 0:
                     dH = dhin
                 else:
-                    dE = dhin if dE is None else dE.add_(dhin)          # (dE aliases d: its last reader, hop Lh-1, is done)
-            dq, de = torch.empty_like(q), torch.empty_like(e)
-            L.check(L.lib().cm_attention_backward(S, N, 64, L.ptr(q), L.ptr(e), L.ptr(attn), L.ptr(d_attn), L.ptr(dq), L.ptr(de),
-                                                  L.current_stream()), "cm_attention_backward")
-        dE.add_(de)
+                    dhin0 = dhin
+            # gradient wrt E = residual term + hop 0's input gradient + attention key side (summed by the attention kernel)
+            # + linear_in's input gradient (summed by the encoder layer's backward): no accumulation passes
+            if Lh == 0:
+                raise L.CommarlError("fused training path needs at least one hop")
+            dq, dE = torch.empty_like(q), torch.empty_like(e)
+            L.check(L.lib().cm_attention_backward(S, N, 64, L.ptr(q), L.ptr(e), L.ptr(attn), L.ptr(d_attn), L.ptr(d_res), L.ptr(dhin0),
+                                                  L.ptr(dq), L.ptr(dE), L.current_stream()), "cm_attention_backward")
         deq, g["attention_layer.linear_in.weight"], _ = _lin_bwd(e, net.attention_layer.linear_in.weight, 0, dq, None, True, False)
-        dE.add_(deq)
         enc1, enc2 = net.encoder._layers[0].linear, net.encoder._output_layers[0].linear
-        da1, g["encoder._output_layers.0.linear.weight"], g["encoder._output_layers.0.linear.bias"] = _lin_bwd(t["a1"], enc2.weight, 0, dE, e, True, True)
+        da1, g["encoder._output_layers.0.linear.weight"], g["encoder._output_layers.0.linear.bias"] = _lin_bwd(t["a1"], enc2.weight, 0, dE, e, True, True,
+                                                                                                                dy_add=deq)
         _, g["encoder._layers.0.linear.weight"], g["encoder._layers.0.linear.bias"] = _lin_bwd(obs2, enc1.weight, 0, da1, t["a1"], False, True)
         ctx.t = None                                                     # free the saved activations
         return (None, None, None, None) + tuple(g.get(n) for n in ctx.names)

@@ -304,17 +304,19 @@ int cm_masked_agg_forward(int32_t S, int32_t N, int32_t E, const float *attn, co
                           const float *chan, int64_t ch_stride, const float *hw, const float *bias, float *out,
                           void *stream);
 /* grads of the op above: given out and d_out returns d_attn [S,N,N], d_hw [S,N,E], d_bias [E] (accumulated with
- * atomics; caller zeroes). */
+ * atomics; caller zeroes).  out_minus (or NULL): the op's output is out - out_minus (the caller holds x = E + H of
+ * comm_base_net.py:107 and E: saves the subtraction pass). */
 int cm_masked_agg_backward(int32_t S, int32_t N, int32_t E, const float *attn, const float *dist_adj,
-                           const float *chan, int64_t ch_stride, const float *hw, const float *out,
+                           const float *chan, int64_t ch_stride, const float *hw, const float *out, const float *out_minus,
                            const float *d_out, float *d_attn, float *d_hw, float *d_bias, void *stream);
 
 /* Attention scores + softmax for the autograd path (attention_module.py:39-49):
  *   m[s,i,:] = softmax_j(q[s,i,:] . e[s,j,:]),  q = linear_in(e) [S,N,E], e [S,N,E], m [S,N,N].
- * backward: d_q, d_e [S,N,E] from d_m [S,N,N] (the d_e returned is only the key-side term). */
+ * backward: d_q, d_e [S,N,E] from d_m [S,N,N] (the d_e returned is only the key-side term) plus, when given, the
+ * other gradients that flow into E: d_e = key-side term + d_e_add0 + d_e_add1 (each [S,N,E] or NULL; must not alias d_e). */
 int cm_attention_forward(int32_t S, int32_t N, int32_t E, const float *q, const float *e, float *m, void *stream);
 int cm_attention_backward(int32_t S, int32_t N, int32_t E, const float *q, const float *e, const float *m,
-                          const float *d_m, float *d_q, float *d_e, void *stream);
+                          const float *d_m, const float *d_e_add0, const float *d_e_add1, float *d_q, float *d_e, void *stream);
 
 /* Weight gradient of a per-agent dense layer over R rows: c[p][q] += sum_r a[r][p] * b[r][q] (c [P,Q] must be
  * zeroed by the caller; accumulated with float atomics), colsum_a[p] += sum_r a[r][p] (or NULL).
@@ -327,14 +329,15 @@ int cm_linear_wgrad(int64_t R, int32_t P, int32_t Q, const float *a, const float
  * w_layout 0: w is nn.Linear's [out,in] (multi_headed_mlp_module.py:134-149, attention_module.py:36);
  * w_layout 1: w is GraphConvolutionModule's [in,out] (graph_conv_module.py:63).  1 <= in, out <= 128.
  *   forward :  y[r][o] = act(bias[o] + sum_k x[r][k] w(k,o)),  act 0 = identity, 1 = tanh; bias may be NULL.
- *   backward:  dz = dy * (1 - y^2) when y != NULL (tanh layer), dz = dy when y == NULL;
+ *   backward:  dz = (dy + dy2) * (1 - y^2) when y != NULL (tanh layer), dz = dy + dy2 when y == NULL; dy2 [R,out] or NULL
+ *              is a second gradient flowing into the same output (saves the caller's accumulation pass);
  *              dx[r][k] = sum_o dz[r][o] w(k,o)   (dx may be NULL: first layer);
  *              dw += dz^T.x in w's own layout and db += colsum(dz) (db may be NULL), float atomics:
  *              the caller zeroes dw / db. */
 int cm_linear_act_forward(int64_t R, int32_t in_dim, int32_t out_dim, const float *x, const float *w, int32_t w_layout,
                           const float *bias, int32_t act, float *y, void *stream);
 int cm_linear_act_backward(int64_t R, int32_t in_dim, int32_t out_dim, const float *x, const float *w, int32_t w_layout,
-                           const float *dy, const float *y, float *dx, float *dw, float *db, void *stream);
+                           const float *dy, const float *dy2, const float *y, float *dx, float *dw, float *db, void *stream);
 
 /* Multi-tensor Adam step with optional gradient-norm clip, two launches for a whole net (csrc/cm_ppo.hip): the vendored
  * torch-1.9 Adam of the reference (com_marl/torch/algos/my_optimizer/_functional.py:72-98, no weight decay / amsgrad) preceded

@@ -269,6 +269,14 @@ def test_fused_linear_act_kernels(R, IN, OUT, act, layout, torch_cuda):
     wr2 = w.clone().requires_grad_()
     _LinearActFn.apply(x, wr2, None if b is None else b, act, layout).backward(dy)
     np.testing.assert_allclose(wr2.grad.cpu().numpy(), w6.grad.cpu().numpy(), rtol=1e-5, atol=2e-6 * float(w6.grad.abs().max()))
+    # a second gradient into the same output, summed inside the kernel (dy2) == the caller adding first
+    from com_marl_amd.nets import _lin_bwd
+    dy_b = torch.randn(R, OUT, generator=g).cuda()
+    yv = y.detach() if act else None
+    dx2, dw2, _ = _lin_bwd(x, w, layout, dy, yv, True, b is not None, dy_add=dy_b)
+    dx1, dw1, _ = _lin_bwd(x, w, layout, dy + dy_b, yv, True, b is not None)
+    np.testing.assert_allclose(dx2.cpu().numpy(), dx1.cpu().numpy(), rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(dw2.cpu().numpy(), dw1.cpu().numpy(), rtol=1e-5, atol=2e-6 * float(dw1.abs().max()))
 
 
 @pytest.mark.parametrize("d,n_agents,residual,hops", [(21, 4, False, 2), (100, 4, True, 2), (100, 6, False, 1), (29, 3, True, 3),

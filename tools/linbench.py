@@ -22,9 +22,9 @@ for K, O in ((128, 64), (64, 128), (64, 64), (21, 128), (64, 32), (32, 128)):
     dw = torch.zeros(O, K, device=dev); db = torch.zeros(O, device=dev)
     gb = lambda *ts: sum(a.numel() for a in ts) * 4 / 1e9
     f = t(lambda: lib.cm_linear_act_forward(R, K, O, x.data_ptr(), w.data_ptr(), 0, b.data_ptr(), 1, y.data_ptr(), st()))
-    bfull = t(lambda: lib.cm_linear_act_backward(R, K, O, x.data_ptr(), w.data_ptr(), 0, dy.data_ptr(), y.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), st()))
-    bnodx = t(lambda: lib.cm_linear_act_backward(R, K, O, x.data_ptr(), w.data_ptr(), 0, dy.data_ptr(), y.data_ptr(), None, dw.data_ptr(), db.data_ptr(), st()))
-    bnoact = t(lambda: lib.cm_linear_act_backward(R, K, O, x.data_ptr(), w.data_ptr(), 0, dy.data_ptr(), None, dx.data_ptr(), dw.data_ptr(), db.data_ptr(), st()))
+    bfull = t(lambda: lib.cm_linear_act_backward(R, K, O, x.data_ptr(), w.data_ptr(), 0, dy.data_ptr(), None, y.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), st()))
+    bnodx = t(lambda: lib.cm_linear_act_backward(R, K, O, x.data_ptr(), w.data_ptr(), 0, dy.data_ptr(), None, y.data_ptr(), None, dw.data_ptr(), db.data_ptr(), st()))
+    bnoact = t(lambda: lib.cm_linear_act_backward(R, K, O, x.data_ptr(), w.data_ptr(), 0, dy.data_ptr(), None, None, dx.data_ptr(), dw.data_ptr(), db.data_ptr(), st()))
     wg = t(lambda: lib.cm_linear_wgrad(R, O, K, dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr(), st()))
     tf = t(lambda: torch.tanh(torch.nn.functional.linear(x, w, b)))
     def tb():
