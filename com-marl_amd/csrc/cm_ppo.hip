@@ -9,6 +9,8 @@
 // N x N mask tile and the N x 64 feature tile are read from HBM exactly once.
 #include <algorithm>
 
+#include <stdlib.h>
+
 #include "cm_internal.h"
 
 namespace cm {
@@ -271,6 +273,179 @@ __global__ __launch_bounds__(TPB) void attn_bwd_kernel(int S, int N, int EPB, co
                 }
         }
         __syncthreads();
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Teams of 4 (the headline config): the two backward kernels above as register kernels.  16 lanes own one env, lane c
+// the four features 4c .. 4c+3 of each of the env's four agent rows: every global access is a 16-byte load / store in
+// 256-byte row segments, ~256 bytes in flight per lane (the generic kernels stage through LDS with 4-byte accesses and
+// run at ~2 TB/s once they read more than three streams).  The 4 x 4 coefficient matrices (normalised A, softmax
+// gradient) are computed one element per lane and shared through LDS.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 f4_fma(float s, const float4 &v, const float4 &a) {
+    return make_float4(fmaf(s, v.x, a.x), fmaf(s, v.y, a.y), fmaf(s, v.z, a.z), fmaf(s, v.w, a.w));
+}
+__device__ __forceinline__ float quad_sum(float v) {      // sum over the 4 lanes of a quad (lanes 4k .. 4k+3)
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void attn_bwd4_kernel(int S, const float *__restrict__ q, const float *__restrict__ e,
+                                                        const float *__restrict__ m, const float *__restrict__ d_m,
+                                                        const float *__restrict__ add0, const float *__restrict__ add1,
+                                                        float *__restrict__ d_q, float *__restrict__ d_e) {
+    __shared__ __attribute__((aligned(16))) float DSs[16][16];
+    const int tid = threadIdx.x, grp = tid >> 4, c = tid & 15;
+    for (int base = blockIdx.x * 16; base < S; base += gridDim.x * 16) {
+        const int s = base + grp;
+        const bool live = s < S;
+        const size_t row0 = (size_t)s * 4 * 64;
+        float4 qv[4], ev[4], a0[4], a1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            qv[i] = ev[i] = a0[i] = a1[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live) {
+                qv[i] = *reinterpret_cast<const float4 *>(q + row0 + i * 64 + 4 * c);
+                ev[i] = *reinterpret_cast<const float4 *>(e + row0 + i * 64 + 4 * c);
+                if (add0) a0[i] = *reinterpret_cast<const float4 *>(add0 + row0 + i * 64 + 4 * c);
+                if (add1) a1[i] = *reinterpret_cast<const float4 *>(add1 + row0 + i * 64 + 4 * c);
+            }
+        }
+        // softmax backward, element (i = c / 4, j = c % 4): dS = m * (dm - sum_j dm m)
+        const float mv = live ? m[(size_t)s * 16 + c] : 0.0f, dv = live ? d_m[(size_t)s * 16 + c] : 0.0f;
+        const float t = quad_sum(dv * mv);
+        __syncthreads();                                   // previous iteration's readers are done
+        DSs[grp][c] = mv * (dv - t);
+        __syncthreads();
+        float ds[16];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float4 v = *reinterpret_cast<const float4 *>(&DSs[grp][4 * k]);
+            ds[4 * k] = v.x; ds[4 * k + 1] = v.y; ds[4 * k + 2] = v.z; ds[4 * k + 3] = v.w;
+        }
+        if (live) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float4 aq = make_float4(0.f, 0.f, 0.f, 0.f), ae = aq;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    aq = f4_fma(ds[4 * i + j], ev[j], aq);                 // dQ[i] += dS[i][j] E[j]
+                    ae = f4_fma(ds[4 * j + i], qv[j], ae);                 // dE[i] += dS[j][i] Q[j]
+                }
+                if (add0) { ae.x += a0[i].x; ae.y += a0[i].y; ae.z += a0[i].z; ae.w += a0[i].w; }
+                if (add1) { ae.x += a1[i].x; ae.y += a1[i].y; ae.z += a1[i].z; ae.w += a1[i].w; }
+                *reinterpret_cast<float4 *>(d_q + row0 + i * 64 + 4 * c) = aq;
+                *reinterpret_cast<float4 *>(d_e + row0 + i * 64 + 4 * c) = ae;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void agg_bwd4_kernel(int S, const float *__restrict__ attn, const float *__restrict__ adj,
+                                                       const float *__restrict__ chan, long ch_stride, const float *__restrict__ hw,
+                                                       const float *__restrict__ outv, const float *__restrict__ out_minus,
+                                                       const float *__restrict__ d_out, float *__restrict__ d_attn,
+                                                       float *__restrict__ d_hw, float *__restrict__ d_bias) {
+    __shared__ __attribute__((aligned(16))) float As[16][16];
+    __shared__ float4 dbs[256];
+    const int tid = threadIdx.x, grp = tid >> 4, c = tid & 15;
+    float4 db = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int base = blockIdx.x * 16; base < S; base += gridDim.x * 16) {
+        const int s = base + grp;
+        const bool live = s < S;
+        const size_t row0 = (size_t)s * 4 * 64;
+        float4 h[4], dp[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            h[i] = dp[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live) {
+                h[i] = *reinterpret_cast<const float4 *>(hw + row0 + i * 64 + 4 * c);
+                float4 y = *reinterpret_cast<const float4 *>(outv + row0 + i * 64 + 4 * c);
+                if (out_minus) {
+                    const float4 u = *reinterpret_cast<const float4 *>(out_minus + row0 + i * 64 + 4 * c);
+                    y.x -= u.x; y.y -= u.y; y.z -= u.z; y.w -= u.w;
+                }
+                const float4 d = *reinterpret_cast<const float4 *>(d_out + row0 + i * 64 + 4 * c);
+                dp[i] = make_float4(d.x * (1.0f - y.x * y.x), d.y * (1.0f - y.y * y.y), d.z * (1.0f - y.z * y.z), d.w * (1.0f - y.w * y.w));   // tanh'
+            }
+        }
+        // normalised A, element (i = c / 4, j = c % 4)
+        float mk = 1.0f, av = 0.0f;
+        if (live) {
+            if (adj) mk *= adj[(size_t)s * 16 + c];
+            if (chan) mk *= chan[(size_t)s * ch_stride + c];
+            av = attn[(size_t)s * 16 + c] * mk;
+        }
+        const float den = quad_sum(av) + 1e-12f;
+        const float an = av / den;
+        __syncthreads();
+        As[grp][c] = an;
+        __syncthreads();
+        float A[16];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float4 v = *reinterpret_cast<const float4 *>(&As[grp][4 * k]);
+            A[4 * k] = v.x; A[4 * k + 1] = v.y; A[4 * k + 2] = v.z; A[4 * k + 3] = v.w;
+        }
+        // d_hw[j] = sum_i A[i][j] dP[i]
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc = f4_fma(A[4 * i + j], dp[i], acc);
+                *reinterpret_cast<float4 *>(d_hw + row0 + j * 64 + 4 * c) = acc;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { db.x += dp[i].x; db.y += dp[i].y; db.z += dp[i].z; db.w += dp[i].w; }
+        // dA[i][j] = sum_o dP[i][o] HW[j][o]: this lane's four features, then a reduce-scatter over the env's 16 lanes
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                v[4 * i + j] = fmaf(dp[i].x, h[j].x, fmaf(dp[i].y, h[j].y, fmaf(dp[i].z, h[j].z, dp[i].w * h[j].w)));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const bool hi = c & 8;
+            const float mine = hi ? v[k + 8] : v[k], other = hi ? v[k] : v[k + 8];
+            v[k] = mine + __shfl_xor(other, 8);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool hi = c & 4;
+            const float mine = hi ? v[k + 4] : v[k], other = hi ? v[k] : v[k + 4];
+            v[k] = mine + __shfl_xor(other, 4);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const bool hi = c & 2;
+            const float mine = hi ? v[k + 2] : v[k], other = hi ? v[k] : v[k + 2];
+            v[k] = mine + __shfl_xor(other, 2);
+        }
+        {
+            const bool hi = c & 1;
+            const float mine = hi ? v[1] : v[0], other = hi ? v[0] : v[1];
+            v[0] = mine + __shfl_xor(other, 1);
+        }
+        // through the renormalisation: dM_ij = mask_ij * (dA_ij - sum_k dA_ik A_ik) / den_i
+        const float da = v[0];
+        const float tt = quad_sum(da * an);
+        if (live) d_attn[(size_t)s * 16 + c] = mk * (da - tt) * (1.0f / den);
+    }
+    if (d_bias) {
+        dbs[tid] = db;
+        __syncthreads();
+        if (tid < 16) {
+            float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int g2 = 0; g2 < 16; ++g2) { const float4 u = dbs[g2 * 16 + tid]; sum.x += u.x; sum.y += u.y; sum.z += u.z; sum.w += u.w; }
+            atomicAdd(d_bias + 4 * tid + 0, sum.x); atomicAdd(d_bias + 4 * tid + 1, sum.y);
+            atomicAdd(d_bias + 4 * tid + 2, sum.z); atomicAdd(d_bias + 4 * tid + 3, sum.w);
+        }
     }
 }
 
@@ -561,6 +736,12 @@ __global__ __launch_bounds__(256) void ppo_surrogate_kernel(int P, int T, int N,
     }
 }
 
+// COMMARL_QUAD_BWD=0: teams of 4 take the generic aggregation / attention backward kernels (A/B and test hook)
+static bool quad_bwd_on() {
+    static const bool v = [] { const char *e = getenv("COMMARL_QUAD_BWD"); return !(e && e[0] == '0'); }();
+    return v;
+}
+
 }  // namespace cm
 
 using namespace cm;
@@ -613,6 +794,13 @@ extern "C" int cm_masked_agg_backward(int32_t S, int32_t N, int32_t E, const flo
     if (!attn || !hw || !out || !d_out || !d_attn || !d_hw) return set_error(CM_ERR_ARG, "cm_masked_agg_backward: null argument");
     if (E != 64) return set_error(CM_ERR_ARG, "cm_masked_agg_backward: embedding dim 64 only");
     if (S <= 0) return CM_OK;
+    if (N == 4 && quad_bwd_on() && !(((uintptr_t)hw | (uintptr_t)out | (uintptr_t)out_minus | (uintptr_t)d_out | (uintptr_t)d_hw) & 15)) {
+        const int blocks = (int)std::min<long>((S + 15) / 16, 2048);
+        hipLaunchKernelGGL(agg_bwd4_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, S, attn, dist_adj, chan, (long)ch_stride, hw, out,
+                           out_minus, d_out, d_attn, d_hw, d_bias);
+        CM_HIP(hipGetLastError());
+        return CM_OK;
+    }
     const size_t lds = agg_lds_bwd(N, E);
     if (lds > 160 * 1024) return set_error(CM_ERR_ARG, "cm_masked_agg_backward: n_agents too large");
     static bool once = false;
@@ -676,6 +864,12 @@ extern "C" int cm_attention_backward(int32_t S, int32_t N, int32_t E, const floa
     if (d_e == d_e_add0 || d_e == d_e_add1) return set_error(CM_ERR_ARG, "cm_attention_backward: d_e must not alias its addends");
     if (E != 64) return set_error(CM_ERR_ARG, "cm_attention_backward: embedding dim 64 only");
     if (S <= 0) return CM_OK;
+    if (N == 4 && quad_bwd_on() && !(((uintptr_t)q | (uintptr_t)e | (uintptr_t)d_e_add0 | (uintptr_t)d_e_add1 | (uintptr_t)d_q | (uintptr_t)d_e) & 15)) {
+        const int blocks = (int)std::min<long>((S + 15) / 16, 4096);
+        hipLaunchKernelGGL(attn_bwd4_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, S, q, e, m, d_m, d_e_add0, d_e_add1, d_q, d_e);
+        CM_HIP(hipGetLastError());
+        return CM_OK;
+    }
     const size_t lds = attn_lds(N, E);
     if (lds > 160 * 1024) return set_error(CM_ERR_ARG, "cm_attention_backward: n_agents too large");
     static bool once = false;
