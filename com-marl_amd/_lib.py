@@ -64,7 +64,7 @@ MLP_MAX_LAYERS = 6
 class FwdSaves(C.Structure):
     """cm_fwd_saves: device pointers of the activations the training forward stores (include/commarl.h)."""
     _fields_ = [("a1", C.c_void_p), ("e", C.c_void_p), ("q", C.c_void_p), ("hw", C.c_void_p * 4), ("h", C.c_void_p * 4),
-                ("x1", C.c_void_p), ("x2", C.c_void_p), ("x3", C.c_void_p), ("out", C.c_void_p)]
+                ("x1", C.c_void_p), ("x2", C.c_void_p), ("x3", C.c_void_p), ("out", C.c_void_p), ("probs", C.c_void_p)]
 
 
 class MlpWeights(C.Structure):
@@ -164,7 +164,7 @@ def lib():
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(L, name)      # AttributeError if the .so does not export a declared symbol
             fn.restype, fn.argtypes = res, args
-        if L.cm_abi_version() != 2:
+        if L.cm_abi_version() != 3:
             raise CommarlError("libcommarl_hip.so ABI version mismatch")
         _lib = L
     return _lib

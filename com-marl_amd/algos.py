@@ -213,8 +213,20 @@ class CentralizedMAPPO:
     def _valid_mask(self, valids, T):
         return torch.arange(T, device=valids.device)[None, :] < valids[:, None]
 
+    @staticmethod
+    def _ll_from_probs(probs, actions):
+        """log-likelihood of the taken joint action from action probabilities [P,T,N,A] -> [P,T] (:561-566)."""
+        return torch.log(probs.gather(-1, actions.long().unsqueeze(-1))).squeeze(-1).sum(-1)
+
+    @staticmethod
+    def _kl_entropy(p_old, p_new):
+        """KL(old || new) mean and entropy mean of `p_new` over ALL padded steps (:440-538) from two probability tensors."""
+        kl = (p_old * (torch.log(p_old) - torch.log(p_new))).sum(-1).mean()
+        ent = -(p_new * torch.log(p_new)).sum(-1).mean(-1).mean()
+        return float(kl), float(ent)
+
     def _compute_loss(self, itr, obs, avail_actions, actions, rewards, valids, baselines, dist_adjs, channels,
-                      advantages=None, old_ll=None, reduce=True):
+                      advantages=None, old_ll=None, reduce=True, logits=None):
         """:390-438.  Returns -(mean over valid steps of clipped surrogate + c * entropy); with
         reduce=False returns (sum, count) for the count-weighted multi-GPU reduction."""
         T = obs.shape[1]
@@ -223,7 +235,8 @@ class CentralizedMAPPO:
         if old_ll is None:
             old_ll = self._old_log_likelihood(obs, actions, dist_adjs, channels)
         if _fused_loss_ok(self.policy, obs, avail_actions, actions, valids):
-            logits = self.policy._logits(obs, dist_adjs, channels)                   # [P,T,N,A]
+            if logits is None:
+                logits = self.policy._logits(obs, dist_adjs, channels)               # [P,T,N,A]
             total, count = _SurrogateFn.apply(logits, actions, old_ll, advantages, valids, self._lr_clip_range,
                                               self._policy_ent_coeff, self._entropy_regularzied)
             return (total, count) if not reduce else total / count
@@ -330,14 +343,32 @@ class CentralizedMAPPO:
         P, T = rewards.shape
         distributed = _dist_ready()
         advantages = self._advantages(rewards, baselines, valids)
-        with torch.no_grad():
-            old_ll0 = self._old_log_likelihood(obs, actions, dist_adjs, channels)
-            loss_before = float(self._compute_loss(itr, obs, avail, actions, rewards, valids, baselines, dist_adjs,
-                                                   channels, advantages, old_ll0))
-            kl_before, _ = self._diagnostics(obs, actions, valids, dist_adjs, channels)
-        self._old_policy.load_state_dict(self.policy.state_dict())                  # :204
-        with torch.no_grad():
-            old_ll = self._old_log_likelihood(obs, actions, dist_adjs, channels)
+        # The reference evaluates the two policies over the full batch eight times per epoch (old log-likelihood twice,
+        # loss before / after, KL + entropy before / after with both nets each).  Only three distinct (weights, batch)
+        # pairs are involved - last epoch's pre-update weights, this epoch's pre-update weights (which the old policy
+        # becomes at :204) and the post-update weights - so three forwards are run and their outputs shared.
+        shared = avail is None and all(hasattr(p, "evaluate_nograd") for p in (self.policy, self._old_policy))
+        if shared:
+            with torch.no_grad():
+                _, p_old0 = self._old_policy.evaluate_nograd(obs, dist_adjs, channels)
+                lg_new, p_new = self.policy.evaluate_nograd(obs, dist_adjs, channels)
+                old_ll0 = self._ll_from_probs(p_old0, actions)
+                loss_before = float(self._compute_loss(itr, obs, avail, actions, rewards, valids, baselines, dist_adjs,
+                                                       channels, advantages, old_ll0, logits=lg_new))
+                kl_before, _ = self._kl_entropy(p_old0, p_new)
+                del p_old0, lg_new
+            self._old_policy.load_state_dict(self.policy.state_dict())              # :204
+            with torch.no_grad():
+                old_ll = self._ll_from_probs(p_new, actions)                         # the old policy now IS the policy
+        else:
+            with torch.no_grad():
+                old_ll0 = self._old_log_likelihood(obs, actions, dist_adjs, channels)
+                loss_before = float(self._compute_loss(itr, obs, avail, actions, rewards, valids, baselines, dist_adjs,
+                                                       channels, advantages, old_ll0))
+                kl_before, _ = self._diagnostics(obs, actions, valids, dist_adjs, channels)
+            self._old_policy.load_state_dict(self.policy.state_dict())              # :204
+            with torch.no_grad():
+                old_ll = self._old_log_likelihood(obs, actions, dist_adjs, channels)
 
         step_size = int(np.ceil(P / self._optimization_n_minibatches))
         if distributed and P < 2 * self._optimization_n_minibatches:
@@ -383,9 +414,16 @@ class CentralizedMAPPO:
         self.policy.sync_weights()
 
         with torch.no_grad():
-            loss_after = float(self._compute_loss(itr, obs, avail, actions, rewards, valids, baselines, dist_adjs,
-                                                  channels, advantages, old_ll))
-            kl, entropy = self._diagnostics(obs, actions, valids, dist_adjs, channels)
+            if shared:
+                lg_after, p_after = self.policy.evaluate_nograd(obs, dist_adjs, channels)
+                loss_after = float(self._compute_loss(itr, obs, avail, actions, rewards, valids, baselines, dist_adjs,
+                                                      channels, advantages, old_ll, logits=lg_after))
+                kl, entropy = self._kl_entropy(p_new, p_after)
+                del lg_after, p_after, p_new
+            else:
+                loss_after = float(self._compute_loss(itr, obs, avail, actions, rewards, valids, baselines, dist_adjs,
+                                                      channels, advantages, old_ll))
+                kl, entropy = self._diagnostics(obs, actions, valids, dist_adjs, channels)
         perf = self._log_performance(itr, paths, returns, valids)
         avg_return = perf["AverageReturn"]
         self.stats = dict(perf, LossBefore=loss_before, LossAfter=loss_after,

@@ -931,12 +931,27 @@ __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, c
         l_x1.template run<true, OUT_F32>(Hp, Hp, XF, SF, RT, wave, lane);
         lds_barrier();
         if (quad_path && a.sv_on) dump_f32<64, TPBW>(XF, SF, a.sv_x1, grow0, rows, tid);
-        for (int r = tid; r < rows; r += TPBW) {
-            const float *x = XF + (size_t)r * SF;
-            float acc = chd.b2 ? chd.b2[0] : 0.0f;
-            for (int k = 0; k < DH; ++k) acc = fmaf(x[k], chd.w2t[k], acc);
-            rs[r] = acc;
-            if (quad_path && a.sv_on && a.sv_out) a.sv_out[grow0 + r] = acc;
+        {
+            // value head 64 -> 1: eight lanes per row, eight features each (one thread per row left 7/8 of the workgroup
+            // idle behind a 64-deep dependent chain of LDS reads)
+            static_assert(DH == 64, "value head split assumes 64 hidden units");
+            const int part = tid & 7;
+            const float4 w0 = *reinterpret_cast<const float4 *>(chd.w2t + 8 * part), w1 = *reinterpret_cast<const float4 *>(chd.w2t + 8 * part + 4);
+            for (int r = tid >> 3; r < rows_cap; r += TPBW / 8) {
+                const float *x = XF + (size_t)min(r, rows - 1) * SF + 8 * part;
+                const float4 x0 = *reinterpret_cast<const float4 *>(x), x1 = *reinterpret_cast<const float4 *>(x + 4);
+                float acc = x0.x * w0.x;
+                acc = fmaf(x0.y, w0.y, acc); acc = fmaf(x0.z, w0.z, acc); acc = fmaf(x0.w, w0.w, acc);
+                acc = fmaf(x1.x, w1.x, acc); acc = fmaf(x1.y, w1.y, acc); acc = fmaf(x1.z, w1.z, acc); acc = fmaf(x1.w, w1.w, acc);
+                acc += __shfl_xor(acc, 1);
+                acc += __shfl_xor(acc, 2);
+                acc += __shfl_xor(acc, 4);
+                acc += chd.b2 ? chd.b2[0] : 0.0f;
+                if (part == 0 && r < rows) {
+                    rs[r] = acc;
+                    if (quad_path && a.sv_on && a.sv_out) a.sv_out[grow0 + r] = acc;
+                }
+            }
         }
         lds_barrier();
         for (int e = tid; e < envs; e += TPBW) {

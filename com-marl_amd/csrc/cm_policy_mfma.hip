@@ -223,6 +223,7 @@ extern "C" int cm_policy_forward_saved(const cm_policy_weights *w, int32_t S, co
     a.S = S; a.N = w->n_agents; a.d = w->d; a.L = w->n_hops;
     a.obs = obs; a.adj = adj; a.chan = chan; a.attn = attn; a.no_residual = w->no_residual;
     set_saves(a, sv);
+    a.probs = sv->probs;
     const mf::PackLayout lo = mf::pack_layout(mf::kpad_of(w->d), w->n_hops, true);
     return policy_forward_h(w, w->mfma_pack + lo.total, a, stream);
 }

@@ -414,9 +414,10 @@ class _FusedNetFn(torch.autograd.Function):
 
 
 @torch.no_grad()
-def _fused_logits_nograd(net, obs, adj, ch):
-    """Policy logits [S,N,A] + attention from the saved-forward kernel with every store but the logits switched off
-    (loss evaluations over the full batch: no activations kept)."""
+def _fused_logits_nograd(net, obs, adj, ch, want_probs=False):
+    """Policy logits [S,N,A] + attention from the saved-forward kernel with every store but the logits (and, on
+    request, the action probabilities) switched off: loss / KL evaluations over the full batch, no activations kept.
+    -> (logits, attn) or, with want_probs, (logits, probs)."""
     N, d, A = net._n_agents, net._dec_obs_dim, net._action_dim
     S = obs.shape[0]
     obs2 = obs.reshape(S * N, d).contiguous()
@@ -424,6 +425,9 @@ def _fused_logits_nograd(net, obs, adj, ch):
     attn = torch.empty(S, N, N, dtype=torch.float32, device=obs.device)
     sv = L.FwdSaves()
     sv.out = out.data_ptr()
+    probs = torch.empty(S, N, A, dtype=torch.float32, device=obs.device) if want_probs else None
+    if want_probs:
+        sv.probs = probs.data_ptr()
     adj_c = None if adj is None else adj.contiguous()
     ch_c = None if ch is None else ch.contiguous()
     with torch.cuda.device(obs.device):
@@ -433,7 +437,7 @@ def _fused_logits_nograd(net, obs, adj, ch):
     if rc == 1:
         raise L.CommarlError("no saved-forward instantiation for this shape")
     L.check(rc, "cm_policy_forward_saved")
-    return out.view(S, N, A), attn
+    return (out.view(S, N, A), probs) if want_probs else (out.view(S, N, A), attn)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -628,6 +632,21 @@ class CommCategoricalMLPPolicy(CommBaseNet):
         E, H, M = self.trunk(obs, adj, ch)
         x = E + H if self.residual else H
         return self.categorical_output_layer(x), M
+
+    @torch.no_grad()
+    def evaluate_nograd(self, obs_n, dist_adj, channels):
+        """One no-grad forward over a batch -> (logits [...,N,A] or None, probs [...,N,A]): both from ONE launch when
+        the fused training forward has an instantiation (the probabilities are the ones act_device returns, bit for bit),
+        else the probabilities from act_device and no logits."""
+        lead, S, obs, adj, ch = self._flatten(obs_n, dist_adj, channels)
+        N = self._n_agents
+        with torch.enable_grad():
+            ok = _fused_train_ok(self, obs) and len(self.categorical_output_layer._layers) == 3
+        if ok:
+            logits, probs = _fused_logits_nograd(self, obs, adj, ch, want_probs=True)
+            return logits.reshape(*lead, N, -1), probs.reshape(*lead, N, -1)
+        _, probs, _ = self.act_device(obs.reshape(S, -1), None, adj, ch, want_actions=False, want_attn=False, policy_step=0)
+        return None, probs.reshape(*lead, N, -1)
 
     def _logits(self, obs_n, dist_adj, channels):
         lead, S, obs, adj, ch = self._flatten(obs_n, dist_adj, channels)

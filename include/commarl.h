@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CM_ABI_VERSION 2
+#define CM_ABI_VERSION 3
 
 enum { CM_PP = 0, CM_CO = 1 };                                  /* scenario */
 enum { CM_CH_FC = 0, CM_CH_FL = 1, CM_CH_IID = 2, CM_CH_GE = 3 }; /* channel model */
@@ -218,10 +218,11 @@ int cm_critic_forward(const cm_critic_weights *w, int32_t n_samples, const float
  *                                       residual (x = E + H_L, comm_categorical_mlp_policy.py:74-77) unless no_residual
  *   x1, x2, x3  head hidden layers: policy [R,128], [R,64], [R,32]; critic x1 [R,64] only
  *   out         policy: logits [R, n_act] (before softmax / avail mask); critic: per-agent value [R] (before the sum)
+ *   probs       policy only: the action probabilities [R, n_act] exactly as cm_policy_forward returns them (no avail mask)
  * attn [S,N,N] is written as in cm_policy_forward.  Returns 1 - nothing done - when there is no saved-forward
  * instantiation for the shape (built for teams of 4, n_hops <= 4, obs dim <= 96): the caller then runs layer by layer. */
 typedef struct cm_fwd_saves {
-    float *a1, *e, *q, *hw[4], *h[4], *x1, *x2, *x3, *out;
+    float *a1, *e, *q, *hw[4], *h[4], *x1, *x2, *x3, *out, *probs;
 } cm_fwd_saves;
 int cm_policy_forward_saved(const cm_policy_weights *w, int32_t n_samples, const float *obs, const float *dist_adj,
                             const float *channels, float *attn, const cm_fwd_saves *sv, void *stream);

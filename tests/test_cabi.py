@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"libcommarl_hip.so does not export {n}"
     assert set(names) == set(_lib.EXPORTED), "ctypes binding and header disagree"
-    assert lib.cm_abi_version() == 2
+    assert lib.cm_abi_version() == 3
     assert isinstance(lib.cm_last_error(), (bytes, type(None)))
 
 

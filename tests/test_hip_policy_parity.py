@@ -398,3 +398,30 @@ def test_fused_training_path_vs_per_layer_autograd(d, hops, residual, masks, tor
         for n_ in b[key]:
             scale = max(1e-6, float(np.abs(b[key][n_]).max()))
             np.testing.assert_allclose(a[key][n_], b[key][n_], rtol=1e-4, atol=1e-5 * scale, err_msg=f"{key} {n_}")
+
+
+def test_evaluate_nograd_shares_one_forward(torch_cuda):
+    """policy.evaluate_nograd (ONE launch giving logits and action probabilities: what train_once shares between the
+    loss, the old log-likelihood and the KL / entropy diagnostics) returns the probabilities of act_device bit for bit
+    and logits whose softmax they are; shapes without a fused training forward fall back to act_device."""
+    torch = torch_cuda
+    from com_marl_amd import nets
+    from com_marl_amd.envs import EnvSpec, _Box, _Discrete
+    torch.manual_seed(5)
+    for n_agents, d in ((4, 21), (6, 21)):
+        spec = EnvSpec(_Box(np.zeros(d * n_agents), np.ones(d * n_agents)), _Discrete(5))
+        pol = nets.CommCategoricalMLPPolicy(spec, n_agents=n_agents, device="cuda:0")
+        P, T = 7, 13
+        obs = torch.rand(P, T, n_agents * d, device="cuda:0")
+        adj = (torch.rand(P, T, n_agents, n_agents, device="cuda:0") < 0.6).float()
+        ch = (torch.rand(P, T, 2, n_agents, n_agents, device="cuda:0") < 0.7).float()
+        logits, probs = pol.evaluate_nograd(obs, adj, ch)
+        _, ref, _ = pol.act_device(obs.reshape(P * T, -1), None, adj.reshape(P * T, n_agents, n_agents),
+                                   ch.reshape(P * T, 2, n_agents, n_agents), want_actions=False, want_attn=False, policy_step=0)
+        assert probs.shape == (P, T, n_agents, 5)
+        assert torch.equal(probs.reshape(P * T, n_agents, 5), ref)
+        if n_agents == 4:
+            assert logits is not None and logits.shape == (P, T, 4, 5)
+            np.testing.assert_allclose(torch.softmax(logits, -1).cpu().numpy(), probs.cpu().numpy(), rtol=1e-5, atol=1e-6)
+        else:
+            assert logits is None
