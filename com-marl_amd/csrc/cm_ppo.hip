@@ -583,7 +583,12 @@ __global__ void gae_kernel(int P, int T, const float *__restrict__ rewards, cons
 // ---------------------------------------------------------------------------------------------
 struct TensorTable { float *p[40]; float *g[40]; float *m[40]; float *v[40]; long n[40]; int count; };
 
-__global__ __launch_bounds__(256) void multi_norm_kernel(TensorTable t, float *norm_sq) {
+// |g|^2 in two deterministic stages (replicas of a data-parallel job must take bit-identical steps from bit-identical
+// all-reduced gradients; a float-atomic sum's order - and with it the clip factor's last bit - varies run to run):
+// block b writes its partial sum to ws[1 + b]; the update kernel adds the NORM_BLOCKS partials in index order.
+constexpr int NORM_BLOCKS = 64;
+
+__global__ __launch_bounds__(256) void multi_norm_kernel(TensorTable t, float *ws) {
     float acc = 0.0f;
     const long stride = (long)gridDim.x * blockDim.x, i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
     for (int k = 0; k < t.count; ++k)
@@ -592,13 +597,20 @@ __global__ __launch_bounds__(256) void multi_norm_kernel(TensorTable t, float *n
     red[threadIdx.x] = acc;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
-    if (threadIdx.x == 0) atomicAdd(norm_sq, red[0]);
+    if (threadIdx.x == 0) ws[1 + blockIdx.x] = red[0];
 }
 
-__global__ __launch_bounds__(256) void multi_adam_kernel(TensorTable t, const float *norm_sq, float *norm_sq_next, float max_norm, float lr,
+__global__ __launch_bounds__(256) void multi_adam_kernel(TensorTable t, float *norm_ws, float max_norm, float lr,
                                                         float b1, float b2, float eps, float bc1, float sqrt_bc2) {
     float coef = 1.0f;
-    if (norm_sq) { const float c = max_norm / (sqrtf(*norm_sq) + 1e-6f); coef = c < 1.0f ? c : 1.0f; }
+    if (norm_ws) {
+        float nsq = 0.0f;
+        for (int b = 0; b < NORM_BLOCKS; ++b) nsq += norm_ws[1 + b];
+        const float c = max_norm / (sqrtf(nsq) + 1e-6f);
+        coef = c < 1.0f ? c : 1.0f;
+        if (blockIdx.x == 0 && threadIdx.x == 0) norm_ws[0] = nsq;
+    }
+    const bool norm_sq = norm_ws != nullptr;
     const float step_size = lr / bc1;
     const long stride = (long)gridDim.x * blockDim.x, i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
     for (int k = 0; k < t.count; ++k)
@@ -611,7 +623,6 @@ __global__ __launch_bounds__(256) void multi_adam_kernel(TensorTable t, const fl
             const float denom = sqrtf(v) / sqrt_bc2 + eps;
             t.p[k][i] = t.p[k][i] - step_size * (m / denom);
         }
-    if (norm_sq_next && blockIdx.x == 0 && threadIdx.x == 0) *norm_sq_next = 0.0f;     // the slot the NEXT step accumulates into
 }
 
 
@@ -747,7 +758,7 @@ static bool quad_bwd_on() {
 using namespace cm;
 
 extern "C" int cm_multi_adam_step(int32_t n, float *const *params, float *const *grads, float *const *exp_avg, float *const *exp_avg_sq,
-                                  const int64_t *sizes, float *norm_sq, float *norm_sq_next, float max_norm, float lr, float beta1,
+                                  const int64_t *sizes, float *norm_ws, float max_norm, float lr, float beta1,
                                   float beta2, float eps, int32_t step, void *stream) {
     if (n < 0 || n > 40) return set_error(CM_ERR_ARG, "cm_multi_adam_step: at most 40 tensors per call");
     if (n == 0) return CM_OK;
@@ -756,11 +767,9 @@ extern "C" int cm_multi_adam_step(int32_t n, float *const *params, float *const 
     t.count = n;
     for (int k = 0; k < n; ++k) { t.p[k] = params[k]; t.g[k] = grads[k]; t.m[k] = exp_avg[k]; t.v[k] = exp_avg_sq[k]; t.n[k] = (long)sizes[k]; }
     const hipStream_t st = (hipStream_t)stream;
-    if (norm_sq) hipLaunchKernelGGL(multi_norm_kernel, dim3(64), dim3(256), 0, st, t, norm_sq);
-    const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
-    hipLaunchKernelGGL(multi_adam_kernel, dim3(64), dim3(256), 0, st, t, (const float *)norm_sq, norm_sq_next, max_norm, lr, beta1, beta2, eps,
+    if (norm_ws) hipLaunchKernelGGL(multi_norm_kernel, dim3(NORM_BLOCKS), dim3(256), 0, st, t, norm_ws);
+    hipLaunchKernelGGL(multi_adam_kernel, dim3(64), dim3(256), 0, st, t, norm_ws, max_norm, lr, beta1, beta2, eps,
                        (float)(1.0 - pow((double)beta1, (double)step)), (float)sqrt(1.0 - pow((double)beta2, (double)step)));
-    (void)bc1; (void)bc2;
     CM_HIP(hipGetLastError());
     return CM_OK;
 }

@@ -50,20 +50,18 @@ class Adam(torch.optim.Optimizer):
             n = len(ps)
             arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])          # noqa: E731
             sizes = (C.c_int64 * n)(*[p.numel() for p in ps])
-            norm_ptr = next_ptr = None
+            norm_ptr = None
             if max_norm is not None:
                 if self._norm is None or self._norm.device != dev:
-                    self._norm = torch.zeros(2, dtype=torch.float32, device=dev)
-                cur = step & 1
-                norm_ptr = self._norm.data_ptr() + 4 * cur
-                next_ptr = self._norm.data_ptr() + 4 * (1 - cur)
-                out = self._norm[cur]
+                    self._norm = torch.zeros(65, dtype=torch.float32, device=dev)   # CM_ADAM_NORM_FLOATS: [0] = |g|^2
+                norm_ptr = self._norm.data_ptr()
+                out = self._norm[0]
             if n > 40:
                 raise L.CommarlError("cm_multi_adam_step takes at most 40 tensors per parameter group")
             with torch.cuda.device(dev):
                 L.check(L.lib().cm_multi_adam_step(
                     n, arr(ps), arr(grads), arr([self.state[p]["exp_avg"] for p in ps]),
-                    arr([self.state[p]["exp_avg_sq"] for p in ps]), sizes, norm_ptr, next_ptr,
+                    arr([self.state[p]["exp_avg_sq"] for p in ps]), sizes, norm_ptr,
                     float(max_norm if max_norm is not None else 0.0), float(group["lr"]), float(b1), float(b2),
                     float(group["eps"]), step, L.current_stream()), "cm_multi_adam_step")
             # the kernel wrote through raw pointers: tell torch (and the nets' weight-pack cache, which keys on the version

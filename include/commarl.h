@@ -342,12 +342,14 @@ int cm_linear_act_backward(int64_t R, int32_t in_dim, int32_t out_dim, const flo
 
 /* Multi-tensor Adam step with optional gradient-norm clip, two launches for a whole net (csrc/cm_ppo.hip): the vendored
  * torch-1.9 Adam of the reference (com_marl/torch/algos/my_optimizer/_functional.py:72-98, no weight decay / amsgrad) preceded
- * - when norm_sq != NULL - by torch.nn.utils.clip_grad_norm_(params, max_norm) (centralized_ma_ppo.py:253-255), the clipped
+ * - when norm_ws != NULL - by torch.nn.utils.clip_grad_norm_(params, max_norm) (centralized_ma_ppo.py:253-255), the clipped
  * gradient written back.  params / grads / exp_avg / exp_avg_sq: HOST arrays of n <= 40 DEVICE pointers, sizes[k] elements
- * each; norm_sq: DEVICE float that must hold 0 on entry and receives |g|^2 before the clip; norm_sq_next (or NULL): a second
- * DEVICE float that is zeroed for the next step (alternate the two).  step = 1, 2, ... (bias correction). */
+ * each; norm_ws: DEVICE workspace of CM_ADAM_NORM_FLOATS floats, no initial contents required: [0] receives |g|^2 before
+ * the clip, the rest holds per-workgroup partial sums added in index order - the norm, and with it the step, is
+ * bit-reproducible (data-parallel replicas stay identical).  step = 1, 2, ... (bias correction). */
+#define CM_ADAM_NORM_FLOATS 65
 int cm_multi_adam_step(int32_t n, float *const *params, float *const *grads, float *const *exp_avg, float *const *exp_avg_sq,
-                       const int64_t *sizes, float *norm_sq, float *norm_sq_next, float max_norm, float lr, float beta1,
+                       const int64_t *sizes, float *norm_ws, float max_norm, float lr, float beta1,
                        float beta2, float eps, int32_t step, void *stream);
 
 /* tensor_utils.discount_cumsum (garage/misc/tensor_utils.py:7-23) per path over a padded
