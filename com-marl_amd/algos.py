@@ -384,19 +384,33 @@ class CentralizedMAPPO:
             ids = torch.as_tensor(shuffled_ids[start:min(start + step_size, P)], device=obs.device)
             minibatches.append((obs[ids], actions[ids], rewards[ids], valids[ids], baselines[ids], sl(dist_adjs, ids),
                                 sl(channels, ids), advantages[ids], old_ll[ids], returns[ids]))
+        # The critic has its own trunk (a-17): its forward / backward (/ optimiser step) share nothing with the policy's
+        # but the minibatch, so they run on a second HIP stream and fill the gaps of the policy's launch chain.
+        import os
+        main = torch.cuda.current_stream(obs.device)
+        side = main
+        if obs.is_cuda and os.environ.get("COMMARL_CRITIC_STREAM", "1") != "0":
+            if getattr(self, "_side_stream", None) is None or self._side_stream.device != obs.device:
+                self._side_stream = torch.cuda.Stream(device=obs.device)
+            side = self._side_stream
         for mini_epoch in range(self._optimization_mini_epochs):
             for o, a, r, v, bl, da, ch, adv_mb, oll_mb, ret_mb in minibatches:
-                loss_sum, n_valid = self._compute_loss(itr, o, None, a, r, v, bl, da, ch, adv_mb, oll_mb, reduce=False)
                 # critic: Gaussian NLL, mean over padded steps (comm_base_critic.py:88-89)
                 n_crit = torch.tensor(float(o.shape[0] * T), device=obs.device)
                 self._baseline_optimizer.zero_grad()
                 self._optimizer.zero_grad()
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    bl_loss = self._baseline_loss(o, ret_mb, da, ch)
+                    (bl_loss * n_crit if distributed else bl_loss).backward()
+                    if not distributed:
+                        self._baseline_optimizer.step()
+                loss_sum, n_valid = self._compute_loss(itr, o, None, a, r, v, bl, da, ch, adv_mb, oll_mb, reduce=False)
                 if distributed:
-                    (self._baseline_loss(o, ret_mb, da, ch) * n_crit).backward()
                     loss_sum.backward()
+                    main.wait_stream(side)
                     self._allreduce_grads(n_valid, n_crit)
                 else:
-                    self._baseline_loss(o, ret_mb, da, ch).backward()
                     (loss_sum / n_valid).backward()
                 if hasattr(self._optimizer, "_norm"):                               # optim.Adam: clip + update in two launches
                     mx = float("inf") if self._clip_grad_norm is None else float(self._clip_grad_norm)
@@ -408,7 +422,9 @@ class CentralizedMAPPO:
                         torch.nn.utils.clip_grad_norm_(self.policy.parameters(), self._clip_grad_norm)
                     grad_norm.append(self.policy.grad_norm())
                     self._optimizer.step()                                           # _optimize (:606-610)
-                self._baseline_optimizer.step()
+                if distributed:
+                    self._baseline_optimizer.step()
+                main.wait_stream(side)
         torch.cuda.synchronize(obs.device)
         epoch_time = time.time() - t_opt
         self.policy.sync_weights()
