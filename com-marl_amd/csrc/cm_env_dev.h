@@ -471,7 +471,8 @@ __device__ __forceinline__ void env_body(const EnvDev &p, const int32_t *__restr
                                          const cm_rng_tape &tape, const cm_step_out &out, int reset_only, int grp, int b_raw,
                                          bool grp_live, int lds_base, int *defer = nullptr) {
     Grp<LPE> g;
-    g.sub = (threadIdx.x & (WAVE - 1)) / LPE; g.sl = threadIdx.x % LPE;
+    const int tx = thread_x();
+    g.sub = (tx & (WAVE - 1)) / LPE; g.sl = tx % LPE;
     const int sl = g.sl;
     const bool valid = grp_live && b_raw < p.B;
     const int b = valid ? b_raw : p.B - 1;            // idle groups shadow the last env and never commit

@@ -25,7 +25,7 @@ template <int POL, int KPAD, int MAXMK>
 __device__ __forceinline__ void policy_body(const mf::FwdArgs &a, const mf::TrunkW &tw, const mf::PolHead &ph, const mh::TrunkH &twh,
                                             const mh::PolHeadH &phh, float *lds, int32_t *act) {
     if constexpr (POL == 0) mf::fwd_body<0, KPAD, MAXMK>(a, tw, ph, mf::CritHead{}, lds, blockIdx.x, act);
-    else mh::fwd_body_h<0, KPAD, MAXMK>(a, twh, phh, mh::CritHeadH{}, reinterpret_cast<unsigned char *>(lds), blockIdx.x, act);
+    else mh::fwd_body_h<0, KPAD, MAXMK, 4, false>(a, twh, phh, mh::CritHeadH{}, reinterpret_cast<unsigned char *>(lds), blockIdx.x, act);
 }
 
 template <int SCEN, int LPE, int KPAD, int MAXMK, int POL>
@@ -43,26 +43,35 @@ __global__ __launch_bounds__(mf::TPB) void rollout_step_kernel(mf::FwdArgs a, mf
 }
 
 // Persistent form: the workgroup keeps its envs for n_steps consecutive steps (policy -> env -> policy ...), pointers
-// advancing by the per-step strides of the time-major trajectory buffers.  No grid-wide synchronisation between steps:
-// workgroups drift apart, so one workgroup's env phase (scalar / LDS work) overlaps its CU neighbour's matrix phases
-// and there is one launch per chunk.  Step t+1 reads what step t wrote (observation, masks, env state) through the
+// advancing by the per-step strides of the time-major trajectory buffers.  No grid-wide synchronisation between steps
+// and one launch per chunk: a step costs the workgroup's own policy + env chain (28.6 us at the headline config), without
+// the grid drain of a launch per step.  Step t+1 reads what step t wrote (observation, masks, env state) through the
 // CU's own write-through L1 / L2: a workgroup-scope release / acquire pair around the workgroup barrier orders them.
 struct ChunkArgs {
     int n_steps;
+    int stagger;              // late start of the second half of the grid, in units of s_sleep 32 (~2048 clocks)
     long long obs, actions, probs, attn, reward, reward_f64, done, details, dist_adj, channels, prey_alive, success, path_len;
 };
 
+// Two waves per SIMD as the single-step kernel: without the bound the compiler hoists every layer's (step-invariant) weight
+// fragment loads out of the step loop, ends at 506 VGPRs and one workgroup per CU - half the grid waits for the other
+// half (62 us per step measured, against 28 for the single-step kernel).
 template <int SCEN, int LPE, int KPAD, int MAXMK, int POL>
-__global__ __launch_bounds__(mf::TPB) void rollout_chunk_kernel(mf::FwdArgs a, mf::TrunkW tw, mf::PolHead ph, mh::TrunkH twh,
+__global__ __launch_bounds__(mf::TPB, 2) void rollout_chunk_kernel(mf::FwdArgs a, mf::TrunkW tw, mf::PolHead ph, mh::TrunkH twh,
                                                                 mh::PolHeadH phh, EnvDev p, cm_step_out out, ChunkArgs c,
                                                                 int act_off) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     int32_t *act = reinterpret_cast<int32_t *>(lds + act_off);
-    const int grp = threadIdx.x / LPE;
     const int envs = min(a.EPB, a.S - (int)blockIdx.x * a.EPB);
-    const bool live = grp < envs;
     const cm_rng_tape no_tape{};
+    // De-phase the workgroups that share a CU: the grid is dispatched round-robin, so workgroup b and b + gridDim / 2 are
+    // neighbours; the late one's matrix phases then meet the early one's env phases for the whole chunk.
+    if (c.stagger > 0 && blockIdx.x >= gridDim.x / 2)
+        for (int i = 0; i < c.stagger; ++i) __builtin_amdgcn_s_sleep(32);
     for (int t = 0; t < c.n_steps; ++t) {
+        asm volatile("" ::: "memory");                                   // keep each step's loads inside the step
+        const int grp = thread_x() / LPE;
+        const bool live = grp < envs;
         mf::FwdArgs at = a;
         at.obs = a.obs + t * c.obs;
         at.adj = a.adj ? a.adj + t * c.dist_adj : nullptr;
@@ -212,7 +221,8 @@ extern "C" int cm_rollout_chunk(cm_env_t h, const cm_policy_weights *w, int32_t 
     if (n_steps < 0) return set_error(CM_ERR_ARG, "cm_rollout_chunk: negative step count");
     if (h && h->cfg.rng_mode == CM_RNG_TAPE) return set_error(CM_ERR_ARG, "cm_rollout_chunk: tape mode steps one launch at a time");
     if (n_steps == 0) return CM_OK;
-    ChunkArgs c{ n_steps, st->obs, st->actions, st->probs, st->attn, st->reward, st->reward_f64, st->done, st->details,
+    static const int stagger = [] { const char *e = getenv("COMMARL_CHUNK_STAGGER"); return e ? atoi(e) : 0; }();
+    ChunkArgs c{ n_steps, stagger, st->obs, st->actions, st->probs, st->attn, st->reward, st->reward_f64, st->done, st->details,
                  st->dist_adj, st->channels, st->prey_alive, st->success, st->path_len };
     return rollout_impl(h, w, obs, nullptr, dist_adj, channels, seed, env_id_offset, policy_step, policy_step_base, greedy, actions,
                         probs, attn, nullptr, out, stream, &c);

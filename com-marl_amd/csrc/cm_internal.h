@@ -18,6 +18,15 @@ int hip_fail(hipError_t e, const char *what);      // -> CM_ERR_HIP
         if (_e != hipSuccess) return ::cm::hip_fail(_e, #call); \
     } while (0)
 
+// threadIdx.x through an opaque register: inside the step loop of the persistent rollout kernel the compiler otherwise
+// hoists every lane-derived address computation of both bodies out of the loop (several hundred live VGPRs: one
+// workgroup per CU, or 256 spilled registers when held to two).  Costs one move in the single-step kernels.
+__device__ __forceinline__ int thread_x() {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+
 // Device-side view of one batched env set (passed to kernels by value).
 struct EnvDev {
     int scen, B, N, M, S, R, W, d, load, max_steps, mpl, L, rc2, channel, add_clock, n_empty, rng_mode, env_id_offset;

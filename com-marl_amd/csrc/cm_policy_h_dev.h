@@ -394,14 +394,17 @@ __host__ __device__ inline LdsMap lds_map(int rows_cap, int epb, int N, int mode
 
 // HEAD 0 = policy, 1 = critic; KH = obs dim rounded up to 32; MAXMK as in mf::fwd_body (-1 teams of 4, 0 small teams on
 // the VALU, > 0 large teams on MFMA tiles); NW = waves per workgroup
-template <int HEAD, int KH, int MAXMK, int NW = 4>
+// SAVES = false compiles the training-forward stores out (the fused rollout kernels: their per-step copy of the argument
+// block then has no dynamically indexed member and stays in registers instead of scratch)
+template <int HEAD, int KH, int MAXMK, int NW = 4, bool SAVES = true>
 __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, const PolHeadH &ph, const CritHeadH &chd,
                                            unsigned char *lds, int blk, int32_t *act_lds) {
     constexpr int TPBW = 64 * NW, NG = 4 * NW;
     static_assert(NW == 4 || (NW == 8 && MAXMK > 0), "8-wave workgroups are built for the large-team path only");
     constexpr bool quad_path = MAXMK < 0;
     constexpr bool big = MAXMK > 0;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = thread_x(), wave = tid >> 6, lane = tid & 63;
+    const bool sv_on = SAVES && a.sv_on;
     const int N = a.N, L = a.L, NN = N * N, NP = N | 1;
     const int s0 = blk * a.EPB;
     const int envs = min(a.EPB, a.S - s0);
@@ -441,7 +444,7 @@ __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, c
     if (quad_path || big) l_enc2.template run<true, OUT_PLANES>(Ap, Ep, nullptr, 0, RT, wave, lane);
     else l_enc2.template run<true, OUT_PLANES | OUT_F32>(Ap, Ep, EF, SF, RT, wave, lane);
     const size_t grow0 = (size_t)s0 * N;                     // first global agent row of this workgroup
-    if (quad_path && a.sv_on) dump_planes<128, TPBW>(Ap, a.sv_a1, grow0, rows, tid);           // encoder hidden layer
+    if (quad_path && sv_on) dump_planes<128, TPBW>(Ap, a.sv_a1, grow0, rows, tid);           // encoder hidden layer
     LayerH<EMB, HEAD == 0 ? H1 : DH, NW> l_x1;               // first head layer (policy 64 -> 128, critic 64 -> 64)
     LayerH<H1, H2, NW> l_h2;
     if (quad_path) l_x1.load(HEAD == 0 ? ph.h1_p : chd.d1_p, HEAD == 0 ? ph.b1 : chd.b1, wave, lane);
@@ -460,10 +463,10 @@ __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, c
             if (L > 1) l_g.load(tw.gcn_p + LayerH<EMB, EMB, NW>::PACK_U4, nullptr, wave, lane);
         }
         if (HEAD == 0) l_h2.load(ph.h2_p, ph.b2, wave, lane);
-        if (a.sv_on) dump_planes<64, TPBW>(Ep, a.sv_e, grow0, rows, tid);
+        if (sv_on) dump_planes<64, TPBW>(Ep, a.sv_e, grow0, rows, tid);
         lds_barrier();
         if (a.stop == 4) return;
-        if (a.sv_on) {
+        if (sv_on) {
             dump_planes<64, TPBW>(Tp, a.sv_q, grow0, rows, tid);
             if (L > 0) dump_f32<64, TPBW>(HW0, SF, a.sv_hw[0], grow0, rows, tid);
         }
@@ -540,12 +543,12 @@ __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, c
             }
             lds_barrier();
             if (a.stop == 61 + l) return;
-            if (a.sv_on && l < 4) dump_planes<64, TPBW>(Hp, a.sv_h[l], grow0, rows, tid);      // hop output (last: + residual)
+            if (sv_on && l < 4) dump_planes<64, TPBW>(Hp, a.sv_h[l], grow0, rows, tid);      // hop output (last: + residual)
             if (!last) {
                 l_g.template run<false, OUT_F32>(Hp, Hp, (l & 1) ? HW0 : HW1, SF, RT, wave, lane);     // H.Wg_{l+1}
                 if (l + 2 < L) l_g.load(tw.gcn_p + (size_t)(l + 2) * LayerH<EMB, EMB, NW>::PACK_U4, nullptr, wave, lane);
                 lds_barrier();
-                if (a.sv_on && l + 1 < 4) dump_f32<64, TPBW>((l & 1) ? HW0 : HW1, SF, a.sv_hw[l + 1], grow0, rows, tid);
+                if (sv_on && l + 1 < 4) dump_f32<64, TPBW>((l & 1) ? HW0 : HW1, SF, a.sv_hw[l + 1], grow0, rows, tid);
             }
         }
     } else {
@@ -866,19 +869,19 @@ __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, c
         l_x1.template run<true, OUT_PLANES>(Hp, Ap, nullptr, 0, RT, wave, lane);             // 64 -> 128 into R1
         lds_barrier();
         l_h2.template run<true, OUT_PLANES>(Ap, Tp, nullptr, 0, RT, wave, lane);             // 128 -> 64 into T
-        if (quad_path && a.sv_on) dump_planes<128, TPBW>(Ap, a.sv_x1, grow0, rows, tid);
+        if (quad_path && sv_on) dump_planes<128, TPBW>(Ap, a.sv_x1, grow0, rows, tid);
         const int A = ph.n_act;
         LayerH<H3, 16, NW> l_h4;                             // 32 -> n_act (<= 8) logits, zero-padded to one feature tile
         l_h4.load(ph.h4_p, ph.b4, wave, lane, A);
         lds_barrier();
         l_h3.template run<true, OUT_PLANES>(Tp, Gp, nullptr, 0, RT, wave, lane);             // 64 -> 32 into EP
-        if (quad_path && a.sv_on) dump_planes<64, TPBW>(Tp, a.sv_x2, grow0, rows, tid);
+        if (quad_path && sv_on) dump_planes<64, TPBW>(Tp, a.sv_x2, grow0, rows, tid);
         lds_barrier();
         if (a.stop == 7) return;
         l_h4.template run<false, OUT_F32>(Gp, Gp, LG, SLG, RT, wave, lane);                  // logits f32 into T
-        if (quad_path && a.sv_on) dump_planes<32, TPBW>(Gp, a.sv_x3, grow0, rows, tid);
+        if (quad_path && sv_on) dump_planes<32, TPBW>(Gp, a.sv_x3, grow0, rows, tid);
         lds_barrier();
-        if (quad_path && a.sv_on && a.sv_out)
+        if (quad_path && sv_on && a.sv_out)
             for (int k = tid; k < rows * A; k += TPBW) { const int r = k / A, cc = k - r * A; a.sv_out[(grow0 + r) * A + cc] = LG[(size_t)r * SLG + cc]; }
         for (int r = tid; r < rows; r += TPBW) {
             float lg[MAX_ACT], p[MAX_ACT];
@@ -930,7 +933,7 @@ __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, c
         float *XF = reinterpret_cast<float *>(lds + lm.r1);                                  // critic: tanh(x1) f32 [rows][SF] in R1
         l_x1.template run<true, OUT_F32>(Hp, Hp, XF, SF, RT, wave, lane);
         lds_barrier();
-        if (quad_path && a.sv_on) dump_f32<64, TPBW>(XF, SF, a.sv_x1, grow0, rows, tid);
+        if (quad_path && sv_on) dump_f32<64, TPBW>(XF, SF, a.sv_x1, grow0, rows, tid);
         {
             // value head 64 -> 1: eight lanes per row, eight features each (one thread per row left 7/8 of the workgroup
             // idle behind a 64-deep dependent chain of LDS reads)
@@ -949,7 +952,7 @@ __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, c
                 acc += chd.b2 ? chd.b2[0] : 0.0f;
                 if (part == 0 && r < rows) {
                     rs[r] = acc;
-                    if (quad_path && a.sv_on && a.sv_out) a.sv_out[grow0 + r] = acc;
+                    if (quad_path && sv_on && a.sv_out) a.sv_out[grow0 + r] = acc;
                 }
             }
         }

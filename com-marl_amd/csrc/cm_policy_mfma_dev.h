@@ -324,7 +324,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &a, const TrunkW &tw, con
                                          int blk, int32_t *act_lds) {
     constexpr int TPBW = 64 * NW, NG = 4 * NW;      // threads and 16-lane groups per workgroup (NW = 4 or 8 waves)
     static_assert(NW == 4 || (NW == 8 && MAXMK > 0), "8-wave workgroups are built for the large-team path only");
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = thread_x(), wave = tid >> 6, lane = tid & 63;
     const int N = a.N, d = a.d, L = a.L, NN = N * N, NP = N | 1;
     const int s0 = blk * a.EPB;
     const int envs = min(a.EPB, a.S - s0);

@@ -247,6 +247,20 @@ class RolloutEngine:
         step by step across the shards (t outer, shard inner): a captured graph submits its nodes in capture order, so
         issuing one shard's whole chain first would start the other shard's chain only after it (measured: ~100 us
         stagger per replay, profiles/r02_trace_short.txt)."""
+        spl = int(os.environ.get("COMMARL_STEPS_PER_LAUNCH", "1"))
+        if spl > 1 and self._fused is not False and self._fused_in_graph:
+            # experiment: several steps per launch (cm_rollout_chunk with a short trip count) - one grid drain per spl steps
+            t = 0
+            while t < n:
+                m = min(spl, n - t)
+                if not self.steps_fused(t, m):
+                    raise L.CommarlError("COMMARL_STEPS_PER_LAUNCH needs the fused chunk kernel")
+                t += m
+            for k, st in enumerate(self.streams):
+                with torch.cuda.stream(st) if st is not None else _null():
+                    self._chunk_tail(k, n)
+            self.join()
+            return
         self.fork()
         for t in range(n):
             for k, st in enumerate(self.streams):
@@ -302,7 +316,7 @@ class RolloutEngine:
         self._graphs[n] = g
         return g
 
-    def run_chunk(self, use_graph=True, n=None):
+    def run_chunk(self, use_graph=True, n=None, weights_synced=False):
         """n steps (default: the whole horizon H) from slot 0, filling slots 0..n-1 (+ slot n of obs / masks), then
         carrying slot n into slot 0 and advancing the sampler's Philox base by n (cm_chunk_tail, per shard): one
         persistent launch per shard where the library has a fused kernel for the shape and the engine was built with
@@ -312,18 +326,18 @@ class RolloutEngine:
         n = self.H if n is None else int(n)
         assert 1 <= n <= self.H
         if self._persistent and self.steps_fused(0, n):
-            self.bump(n)
             self.fork()
             for k, st in enumerate(self.streams):
                 with torch.cuda.stream(st) if st is not None else _null():
-                    self._wrap_part(k, n)
+                    self._chunk_tail(k, n)                  # slot n -> slot 0 and the Philox base, one launch per shard
             self.join()
             return
         if not use_graph:
             self._chunk(n)
             return
         g = self._graphs.get(n) or self.prepare_graph(n)
-        self.policy.sync_weights()          # in-place refresh of the weight pack the graph points at
+        if not weights_synced:              # in-place refresh of the weight pack the graph points at; a caller that steps
+            self.policy.sync_weights()      # many chunks between optimiser steps syncs once itself (~15 us of host time)
         g.replay()
 
     def invalidate_graphs(self):
