@@ -36,8 +36,9 @@ __global__ __launch_bounds__(mf::TPB) void rollout_step_kernel(mf::FwdArgs a, mf
     int32_t *act = reinterpret_cast<int32_t *>(lds + act_off);           // [EPB*N] sampled actions, behind the policy tiles
     policy_body<POL, KPAD, MAXMK>(a, tw, ph, twh, phh, lds, act);
     __syncthreads();                                                     // actions visible; the policy tiles are dead
-    const int grp = threadIdx.x / LPE;
+    const int tx = thread_x(), grp = tx / LPE;
     const int envs = min(a.EPB, a.S - (int)blockIdx.x * a.EPB);
+    if ((tx & ~63) / LPE >= envs) return;                               // a wave with no env of its own (the env body syncs wave-locally)
     const bool live = grp < envs;
     env_body<SCEN, LPE>(p, nullptr, act + (live ? grp : 0) * p.N, tape, out, 0, grp, blockIdx.x * a.EPB + (live ? grp : 0), live, 0);
 }
@@ -93,7 +94,8 @@ __global__ __launch_bounds__(mf::TPB, 2) void rollout_chunk_kernel(mf::FwdArgs a
         if (ot.prey_alive) ot.prey_alive += t * c.prey_alive;
         if (ot.success) ot.success += t * c.success;
         if (ot.path_len) ot.path_len += t * c.path_len;
-        env_body<SCEN, LPE>(p, nullptr, act + (live ? grp : 0) * p.N, no_tape, ot, 0, grp, blockIdx.x * a.EPB + (live ? grp : 0), live, 0);
+        if ((thread_x() & ~63) / LPE < envs)                             // waves without an env of their own skip to the barrier
+            env_body<SCEN, LPE>(p, nullptr, act + (live ? grp : 0) * p.N, no_tape, ot, 0, grp, blockIdx.x * a.EPB + (live ? grp : 0), live, 0);
         // workgroup-scope release / acquire around the barrier: every wave's stores of this step are performed
         // (vmcnt drained) before any wave issues the next step's loads.  All waves of a workgroup share their CU's
         // write-through vector L1, so no cache maintenance is needed (an agent-scope pair would write back and

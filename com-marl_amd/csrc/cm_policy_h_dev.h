@@ -878,6 +878,15 @@ __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, c
         if (quad_path && sv_on) dump_planes<64, TPBW>(Tp, a.sv_x2, grow0, rows, tid);
         lds_barrier();
         if (a.stop == 7) return;
+        // the sampler's uniforms do not depend on the logits: the last wave (idle in the 32 -> n_act layer unless the
+        // workgroup has NW row tiles) draws them now, off the critical path of the softmax / selection chain below
+        const bool draw = (a.actions || act_lds) && !a.greedy;
+        if (draw && wave == NW - 1)
+            for (int r = lane; r < rows; r += 64) {
+                const int e = r / N, i = r - e * N;
+                const u32x4 xr = philox4x32_10((uint32_t)(a.env_id_offset + s0 + e), draw_step, SITE_ACTION, (uint32_t)i, a.key0, a.key1);
+                rs[r] = unit_f32(xr.x);
+            }
         l_h4.template run<false, OUT_F32>(Gp, Gp, LG, SLG, RT, wave, lane);                  // logits f32 into T
         if (quad_path && sv_on) dump_planes<32, TPBW>(Gp, a.sv_x3, grow0, rows, tid);
         lds_barrier();
@@ -914,10 +923,7 @@ __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, c
 #pragma unroll
                     for (int cc = 1; cc < MAX_ACT; ++cc) if (cc < A && p[cc] > best) { best = p[cc]; act = cc; }
                 } else {
-                    const int e = r / N, i = r - e * N;
-                    const u32x4 xr = philox4x32_10((uint32_t)(a.env_id_offset + s0 + e), draw_step, SITE_ACTION, (uint32_t)i,
-                                                   a.key0, a.key1);
-                    const float u = unit_f32(xr.x);
+                    const float u = rs[r];
                     float acc = 0.0f;
                     int sel = -1, lastc = 0;
 #pragma unroll
