@@ -747,6 +747,12 @@ __global__ __launch_bounds__(256) void ppo_surrogate_kernel(int P, int T, int N,
     }
 }
 
+// cm_ppo_mfma.hip: teams of 8 .. 128 on the matrix cores (return 1 = shape not covered)
+int agg_bwd_mfma(int S, int N, const float *attn, const float *adj, const float *chan, long ch_stride, const float *hw, const float *out,
+                 const float *out_minus, const float *d_out, float *d_attn, float *d_hw, float *d_bias, void *stream);
+int attn_bwd_mfma(int S, int N, const float *q, const float *e, const float *m, const float *d_m, const float *add0, const float *add1,
+                  float *d_q, float *d_e, void *stream);
+
 // COMMARL_QUAD_BWD=0: teams of 4 take the generic aggregation / attention backward kernels (A/B and test hook)
 static bool quad_bwd_on() {
     static const bool v = [] { const char *e = getenv("COMMARL_QUAD_BWD"); return !(e && e[0] == '0'); }();
@@ -810,6 +816,8 @@ extern "C" int cm_masked_agg_backward(int32_t S, int32_t N, int32_t E, const flo
         CM_HIP(hipGetLastError());
         return CM_OK;
     }
+    if (const int rc = agg_bwd_mfma(S, N, attn, dist_adj, chan, (long)ch_stride, hw, out, out_minus, d_out, d_attn, d_hw, d_bias, stream); rc != 1)
+        return rc;
     const size_t lds = agg_lds_bwd(N, E);
     if (lds > 160 * 1024) return set_error(CM_ERR_ARG, "cm_masked_agg_backward: n_agents too large");
     static bool once = false;
@@ -879,6 +887,7 @@ extern "C" int cm_attention_backward(int32_t S, int32_t N, int32_t E, const floa
         CM_HIP(hipGetLastError());
         return CM_OK;
     }
+    if (const int rc = attn_bwd_mfma(S, N, q, e, m, d_m, d_e_add0, d_e_add1, d_q, d_e, stream); rc != 1) return rc;
     const size_t lds = attn_lds(N, E);
     if (lds > 160 * 1024) return set_error(CM_ERR_ARG, "cm_attention_backward: n_agents too large");
     static bool once = false;

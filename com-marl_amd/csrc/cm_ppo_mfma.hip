@@ -1,0 +1,293 @@
+// cm_ppo_mfma.hip - backward of the masked aggregation and of the attention softmax for teams of 8 .. 128 agents (the
+// PPO update's N x N operators; reference: comm_base_net.py:99-105 + graph_conv_module.py:63-70, attention_module.py:38-47
+// and their autograd).  Per env these are two skinny GEMM pairs,
+//     aggregation:  d_hw = A^T . dP   [N,N]^T [N,64]       dA = dP . hw^T   [N,64] [64,N]
+//     attention  :  d_q  = dS . e     [N,N]   [N,64]       d_e = dS^T . q   [N,N]^T [N,64]
+// which the first-generation kernels (cm_ppo.hip, kept for N < 8) ran as scalar loops over LDS: 53 ms per launch at
+// N = 72 (4.9 M agent rows), 55 % of that config's update.  Here a workgroup owns one env at a time, the N x N matrix and
+// the two [N,64] tiles sit in LDS once, and all four products run on v_mfma_f32_16x16x4_f32; the softmax / renormalisation
+// gradients are finished in the accumulator registers (16-lane row reductions), so the N x N gradient goes straight to HBM.
+// The kernels are HBM-bound by construction (256 N^2 FLOP against ~(1024 N + 16 N^2) bytes per env).
+#include <stdint.h>
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "cm_internal.h"
+
+namespace cm {
+namespace pm {
+
+constexpr int TPB = 256, E = 64;
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+__host__ __device__ inline int np_of(int N) { return (N + 15) & ~15; }
+// row stride of the N x N tile: == 16 (mod 32) words, so that a k-step's four rows (lanes g) fall in four different
+// 16-bank groups when the 16 lanes c read along a row
+__host__ __device__ inline int sa_of(int NP) { return (NP % 32 == 16) ? NP : NP + 16; }
+constexpr int SP = 68;                      // [N,64] tile read with lanes c along ROWS (4 * odd: conflict-free), aggregation
+constexpr int SR = 80;                      // [N,64] tile read with lanes c along a row (== 16 mod 32), attention
+
+__device__ __forceinline__ float row_sum16(float v) {       // sum over the 16 lanes c of a lane group (same g)
+    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+    return v;
+}
+__device__ __forceinline__ v4f mfma4(float a, float b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// masked aggregation backward.  MAXNT = row tiles the accumulator arrays are sized for (N <= 16 MAXNT).
+// ---------------------------------------------------------------------------------------------------------------
+template <int MAXNT>
+__global__ __launch_bounds__(TPB) void agg_bwd_kernel(int S, int N, const float *__restrict__ attn, const float *__restrict__ adj,
+                                                     const float *__restrict__ chan, long ch_stride, const float *__restrict__ hw,
+                                                     const float *__restrict__ outv, const float *__restrict__ out_minus,
+                                                     const float *__restrict__ d_out, float *__restrict__ d_attn,
+                                                     float *__restrict__ d_hw, float *__restrict__ d_bias) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int NP = np_of(N), NT = NP >> 4, SA = sa_of(NP), NN = N * N;
+    float *A = lds;                                       // [NP][SA] normalised A; rows / columns >= N stay zero
+    float *HW = A + (size_t)NP * SA;                      // [NP][SP]
+    float *DP = HW + (size_t)NP * SP;                     // [NP][SP] dL/d(pre-activation)
+    float *den = DP + (size_t)NP * SP;                    // [NP]
+    float *dbs = den + NP;                                // [TPB / 64][64] bias partials
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
+    const int o = tid & 63, rg = tid >> 6;
+    float dbias_acc = 0.0f;
+    for (int k = tid; k < NP * SA + 2 * NP * SP; k += TPB) lds[k] = 0.0f;
+    __syncthreads();
+    for (int s = blockIdx.x; s < S; s += gridDim.x) {
+        const size_t base = (size_t)s * NN, row0 = (size_t)s * N * E;
+        for (int k = tid; k < NN; k += TPB) {
+            const int i = k / N, j = k - i * N;
+            float m = 1.0f;
+            if (adj) m *= adj[base + k];
+            if (chan) m *= chan[(size_t)s * ch_stride + k];
+            A[(size_t)i * SA + j] = attn[base + k] * m;
+        }
+        for (int k = tid; k < N * (E / 4); k += TPB) {
+            const int r = k >> 4, q = k & 15;
+            const size_t at = row0 + (size_t)r * E + 4 * q;
+            const float4 h = *reinterpret_cast<const float4 *>(hw + at);
+            float4 y = *reinterpret_cast<const float4 *>(outv + at);
+            if (out_minus) { const float4 u = *reinterpret_cast<const float4 *>(out_minus + at); y.x -= u.x; y.y -= u.y; y.z -= u.z; y.w -= u.w; }
+            const float4 d = *reinterpret_cast<const float4 *>(d_out + at);
+            *reinterpret_cast<float4 *>(HW + (size_t)r * SP + 4 * q) = h;
+            *reinterpret_cast<float4 *>(DP + (size_t)r * SP + 4 * q) =
+                make_float4(d.x * (1.0f - y.x * y.x), d.y * (1.0f - y.y * y.y), d.z * (1.0f - y.z * y.z), d.w * (1.0f - y.w * y.w));   // tanh'
+        }
+        __syncthreads();
+        for (int r = tid; r < N; r += TPB) {
+            float *ar = A + (size_t)r * SA;
+            float sum = 0.0f;
+            for (int j = 0; j < N; ++j) sum += ar[j];
+            const float dn = sum + 1e-12f;
+            den[r] = dn;
+            for (int j = 0; j < N; ++j) ar[j] = ar[j] / dn;
+        }
+        if (d_bias) for (int r = rg; r < N; r += TPB / 64) dbias_acc += DP[(size_t)r * SP + o];
+        __syncthreads();
+        // ---- d_hw = A^T . dP: this wave's 16 output features, every row tile ----
+        {
+            v4f acc[MAXNT];
+#pragma unroll
+            for (int t = 0; t < MAXNT; ++t) acc[t] = (v4f){ 0.f, 0.f, 0.f, 0.f };
+            for (int kk = 0; kk < NP / 4; ++kk) {                                 // k = source row i = 4 kk + g
+                const float b = DP[(size_t)(4 * kk + g) * SP + 16 * wave + c];
+                const float *ar = A + (size_t)(4 * kk + g) * SA + c;
+#pragma unroll
+                for (int t = 0; t < MAXNT; ++t)
+                    if (t < NT) acc[t] = mfma4(ar[16 * t], b, acc[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < MAXNT; ++t)
+                if (t < NT) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * t + 4 * g + r;
+                        if (row < N) d_hw[row0 + (size_t)row * E + 16 * wave + c] = acc[t][r];
+                    }
+                }
+        }
+        // ---- dA = dP . hw^T, one row tile per wave at a time; through the renormalisation in registers:
+        //      dM_ij = mask_ij (dA_ij - sum_k dA_ik A_ik) / den_i ----
+        for (int it = wave; it < NT; it += TPB / 64) {
+            v4f acc[MAXNT];
+#pragma unroll
+            for (int t = 0; t < MAXNT; ++t) acc[t] = (v4f){ 0.f, 0.f, 0.f, 0.f };
+            for (int kk = 0; kk < E / 4; ++kk) {                                  // k = feature 4 kk + g
+                const float a = DP[(size_t)(16 * it + c) * SP + 4 * kk + g];
+                const float *hr = HW + (size_t)c * SP + 4 * kk + g;
+#pragma unroll
+                for (int t = 0; t < MAXNT; ++t)
+                    if (t < NT) acc[t] = mfma4(a, hr[(size_t)16 * t * SP], acc[t]);
+            }
+            float tt[4] = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+            for (int t = 0; t < MAXNT; ++t)
+                if (t < NT) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tt[r] = fmaf(acc[t][r], A[(size_t)(16 * it + 4 * g + r) * SA + 16 * t + c], tt[r]);
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tt[r] = row_sum16(tt[r]);
+#pragma unroll
+            for (int t = 0; t < MAXNT; ++t)
+                if (t < NT) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 16 * it + 4 * g + r, j = 16 * t + c;
+                        if (i < N && j < N) {
+                            const size_t k = (size_t)i * N + j;
+                            float m = 1.0f;
+                            if (adj) m *= adj[base + k];
+                            if (chan) m *= chan[(size_t)s * ch_stride + k];
+                            d_attn[base + k] = m * (acc[t][r] - tt[r]) * (1.0f / den[i]);
+                        }
+                    }
+                }
+        }
+        __syncthreads();
+    }
+    if (d_bias) {
+        dbs[rg * 64 + o] = dbias_acc;
+        __syncthreads();
+        if (rg == 0) {
+            float v = 0.0f;
+            for (int q = 0; q < TPB / 64; ++q) v += dbs[q * 64 + o];
+            atomicAdd(d_bias + o, v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// attention softmax backward:  dS = M (dM - rowsum(dM M));  d_q = dS . e;  d_e = dS^T . q (+ two optional addends)
+// ---------------------------------------------------------------------------------------------------------------
+template <int MAXNT>
+__global__ __launch_bounds__(TPB) void attn_bwd_kernel(int S, int N, const float *__restrict__ q, const float *__restrict__ e,
+                                                      const float *__restrict__ m, const float *__restrict__ d_m,
+                                                      const float *__restrict__ add0, const float *__restrict__ add1,
+                                                      float *__restrict__ d_q, float *__restrict__ d_e) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int NP = np_of(N), NT = NP >> 4, SA = sa_of(NP), NN = N * N;
+    float *DS = lds;                                      // [NP][SA]; rows / columns >= N stay zero
+    float *Q = DS + (size_t)NP * SA;                      // [NP][SR]
+    float *K = Q + (size_t)NP * SR;                       // [NP][SR]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
+    for (int k = tid; k < NP * SA + 2 * NP * SR; k += TPB) lds[k] = 0.0f;
+    __syncthreads();
+    for (int s = blockIdx.x; s < S; s += gridDim.x) {
+        const size_t base = (size_t)s * NN, row0 = (size_t)s * N * E;
+        for (int k = tid; k < N * (E / 4); k += TPB) {
+            const int r = k >> 4, x = k & 15;
+            *reinterpret_cast<float4 *>(Q + (size_t)r * SR + 4 * x) = *reinterpret_cast<const float4 *>(q + row0 + (size_t)r * E + 4 * x);
+            *reinterpret_cast<float4 *>(K + (size_t)r * SR + 4 * x) = *reinterpret_cast<const float4 *>(e + row0 + (size_t)r * E + 4 * x);
+        }
+        // softmax backward, 16 lanes per row
+        for (int r = tid >> 4; r < N; r += TPB / 16) {
+            const float *mr = m + base + (size_t)r * N, *dr = d_m + base + (size_t)r * N;
+            float t = 0.0f;
+            for (int j = c; j < N; j += 16) t = fmaf(dr[j], mr[j], t);
+            t = row_sum16(t);
+            for (int j = c; j < N; j += 16) DS[(size_t)r * SA + j] = mr[j] * (dr[j] - t);
+        }
+        __syncthreads();
+        // this wave's 16 output features of both products, every row tile
+        v4f aq[MAXNT], ae[MAXNT];
+#pragma unroll
+        for (int t = 0; t < MAXNT; ++t) { aq[t] = (v4f){ 0.f, 0.f, 0.f, 0.f }; ae[t] = aq[t]; }
+        for (int kk = 0; kk < NP / 4; ++kk) {
+            const float be = K[(size_t)(4 * kk + g) * SR + 16 * wave + c];        // e[j = 4 kk + g]
+            const float bq = Q[(size_t)(4 * kk + g) * SR + 16 * wave + c];        // q[i = 4 kk + g]
+            const float *dsr = DS + (size_t)c * SA + 4 * kk + g;                   // dS[i = 16 t + c][j = 4 kk + g]
+            const float *dst = DS + (size_t)(4 * kk + g) * SA + c;                 // dS[i = 4 kk + g][j = 16 t + c]
+#pragma unroll
+            for (int t = 0; t < MAXNT; ++t)
+                if (t < NT) {
+                    aq[t] = mfma4(dsr[(size_t)16 * t * SA], be, aq[t]);
+                    ae[t] = mfma4(dst[16 * t], bq, ae[t]);
+                }
+        }
+#pragma unroll
+        for (int t = 0; t < MAXNT; ++t)
+            if (t < NT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * t + 4 * g + r;
+                    if (row < N) {
+                        const size_t at = row0 + (size_t)row * E + 16 * wave + c;
+                        d_q[at] = aq[t][r];
+                        float v = ae[t][r];
+                        if (add0) v += add0[at];
+                        if (add1) v += add1[at];
+                        d_e[at] = v;
+                    }
+                }
+            }
+        __syncthreads();
+    }
+}
+
+static size_t agg_lds(int N) { const int NP = np_of(N); return ((size_t)NP * sa_of(NP) + 2 * (size_t)NP * SP + NP + TPB) * sizeof(float); }
+static size_t attn_lds(int N) { const int NP = np_of(N); return ((size_t)NP * sa_of(NP) + 2 * (size_t)NP * SR) * sizeof(float); }
+
+static int blocks_for(int S, size_t lds) {
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds, 1)));
+    return (int)std::min<long>(S, 256L * per_cu);
+}
+
+template <int MAXNT>
+static int launch_agg(int S, int N, const float *attn, const float *adj, const float *chan, long ch_stride, const float *hw, const float *out,
+                      const float *out_minus, const float *d_out, float *d_attn, float *d_hw, float *d_bias, hipStream_t st) {
+    const size_t lds = agg_lds(N);
+    static bool once = false;
+    if (!once) { CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_bwd_kernel<MAXNT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
+    hipLaunchKernelGGL(agg_bwd_kernel<MAXNT>, dim3(blocks_for(S, lds)), dim3(TPB), lds, st, S, N, attn, adj, chan, ch_stride, hw, out, out_minus,
+                       d_out, d_attn, d_hw, d_bias);
+    CM_HIP(hipGetLastError());
+    return CM_OK;
+}
+
+template <int MAXNT>
+static int launch_attn(int S, int N, const float *q, const float *e, const float *m, const float *d_m, const float *add0, const float *add1,
+                       float *d_q, float *d_e, hipStream_t st) {
+    const size_t lds = attn_lds(N);
+    static bool once = false;
+    if (!once) { CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_bwd_kernel<MAXNT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
+    hipLaunchKernelGGL(attn_bwd_kernel<MAXNT>, dim3(blocks_for(S, lds)), dim3(TPB), lds, st, S, N, q, e, m, d_m, add0, add1, d_q, d_e);
+    CM_HIP(hipGetLastError());
+    return CM_OK;
+}
+
+}  // namespace pm
+
+static bool mfma_bwd_on() {
+    static const bool v = [] { const char *e = getenv("COMMARL_NXN_BWD"); return !(e && e[0] == 'o'); }();   // "old": first-generation kernels
+    return v;
+}
+
+// Return 1 when the shape is not covered (N < 8, N > 128, unaligned rows): the caller runs the first-generation kernel.
+int agg_bwd_mfma(int S, int N, const float *attn, const float *adj, const float *chan, long ch_stride, const float *hw, const float *out,
+                 const float *out_minus, const float *d_out, float *d_attn, float *d_hw, float *d_bias, void *stream) {
+    if (!mfma_bwd_on() || N < 8 || N > 128) return 1;
+    if (((uintptr_t)hw | (uintptr_t)out | (uintptr_t)out_minus | (uintptr_t)d_out) & 15) return 1;
+    if (pm::agg_lds(N) > 160 * 1024) return 1;
+    const hipStream_t st = (hipStream_t)stream;
+    const int NT = pm::np_of(N) / 16;
+    if (NT <= 2) return pm::launch_agg<2>(S, N, attn, adj, chan, ch_stride, hw, out, out_minus, d_out, d_attn, d_hw, d_bias, st);
+    if (NT <= 5) return pm::launch_agg<5>(S, N, attn, adj, chan, ch_stride, hw, out, out_minus, d_out, d_attn, d_hw, d_bias, st);
+    return pm::launch_agg<8>(S, N, attn, adj, chan, ch_stride, hw, out, out_minus, d_out, d_attn, d_hw, d_bias, st);
+}
+
+int attn_bwd_mfma(int S, int N, const float *q, const float *e, const float *m, const float *d_m, const float *add0, const float *add1,
+                  float *d_q, float *d_e, void *stream) {
+    if (!mfma_bwd_on() || N < 8 || N > 128) return 1;
+    if (((uintptr_t)q | (uintptr_t)e) & 15) return 1;
+    if (pm::attn_lds(N) > 160 * 1024) return 1;
+    const hipStream_t st = (hipStream_t)stream;
+    const int NT = pm::np_of(N) / 16;
+    if (NT <= 2) return pm::launch_attn<2>(S, N, q, e, m, d_m, add0, add1, d_q, d_e, st);
+    if (NT <= 5) return pm::launch_attn<5>(S, N, q, e, m, d_m, add0, add1, d_q, d_e, st);
+    return pm::launch_attn<8>(S, N, q, e, m, d_m, add0, add1, d_q, d_e, st);
+}
+
+}  // namespace cm

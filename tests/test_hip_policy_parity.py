@@ -90,7 +90,8 @@ def _agg_torch(attn, adj, ch, hw, bias):
     return torch.tanh(torch.matmul(A, hw) + bias)
 
 
-@pytest.mark.parametrize("S,N", [(37, 4), (5, 24), (3, 54), (2, 72), (9, 3), (130, 8)])
+@pytest.mark.parametrize("S,N", [(37, 4), (5, 24), (3, 54), (2, 72), (9, 3), (130, 8), (4, 9), (3, 16), (2, 100), (2, 128), (2100, 24),
+                                 (700, 54)])
 def test_masked_aggregate_forward_backward(S, N, torch_cuda):
     torch = torch_cuda
     from com_marl_amd.nets import masked_aggregate
@@ -180,7 +181,8 @@ def test_returns_gae_kernels(torch_cuda):
     np.testing.assert_allclose(adv.cpu().numpy(), want, rtol=2e-3, atol=2e-3)
 
 
-@pytest.mark.parametrize("S,N", [(50, 4), (7, 24), (3, 54), (2, 72), (11, 3)])
+@pytest.mark.parametrize("S,N", [(50, 4), (7, 24), (3, 54), (2, 72), (11, 3), (130, 8), (4, 9), (3, 16), (2, 100), (2, 128), (2100, 24),
+                                 (700, 54)])
 def test_attention_softmax_op(S, N, torch_cuda):
     """fused scores+softmax (cm_attention_forward/backward) vs the plain PyTorch f32 ops it replaces"""
     torch = torch_cuda
