@@ -52,37 +52,71 @@ __global__ __launch_bounds__(TPB) void agg_bwd_kernel(int S, int N, const float 
     float *dbs = den + NP;                                // [TPB / 64][64] bias partials
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
     const int o = tid & 63, rg = tid >> 6;
+    const float rcpN = 1.0f / (float)N;
     float dbias_acc = 0.0f;
     for (int k = tid; k < NP * SA + 2 * NP * SP; k += TPB) lds[k] = 0.0f;
     __syncthreads();
     for (int s = blockIdx.x; s < S; s += gridDim.x) {
         const size_t base = (size_t)s * NN, row0 = (size_t)s * N * E;
-        for (int k = tid; k < NN; k += TPB) {
-            const int i = k / N, j = k - i * N;
-            float m = 1.0f;
-            if (adj) m *= adj[base + k];
-            if (chan) m *= chan[(size_t)s * ch_stride + k];
-            A[(size_t)i * SA + j] = attn[base + k] * m;
-        }
-        for (int k = tid; k < N * (E / 4); k += TPB) {
-            const int r = k >> 4, q = k & 15;
-            const size_t at = row0 + (size_t)r * E + 4 * q;
-            const float4 h = *reinterpret_cast<const float4 *>(hw + at);
-            float4 y = *reinterpret_cast<const float4 *>(outv + at);
-            if (out_minus) { const float4 u = *reinterpret_cast<const float4 *>(out_minus + at); y.x -= u.x; y.y -= u.y; y.z -= u.z; y.w -= u.w; }
-            const float4 d = *reinterpret_cast<const float4 *>(d_out + at);
-            *reinterpret_cast<float4 *>(HW + (size_t)r * SP + 4 * q) = h;
-            *reinterpret_cast<float4 *>(DP + (size_t)r * SP + 4 * q) =
-                make_float4(d.x * (1.0f - y.x * y.x), d.y * (1.0f - y.y * y.y), d.z * (1.0f - y.z * y.z), d.w * (1.0f - y.w * y.w));   // tanh'
+        // every load of a batch is issued before the first LDS write: one HBM round trip per batch, not per element
+        // (the straightforward loop waited ~2 us twenty times per env at N = 72)
+        {
+            const float4 *h4 = reinterpret_cast<const float4 *>(hw + row0), *y4 = reinterpret_cast<const float4 *>(outv + row0);
+            const float4 *u4 = out_minus ? reinterpret_cast<const float4 *>(out_minus + row0) : nullptr;
+            const float4 *d4 = reinterpret_cast<const float4 *>(d_out + row0);
+            const int n4 = N * (E / 4);                                            // <= 256 MAXNT float4 per operand
+            constexpr int U4 = MAXNT <= 5 ? MAXNT : 4;
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k0 = tid; k0 < n4; k0 += U4 * TPB) {
+                float4 hv[U4], yv[U4], uv[U4], dv[U4];
+#pragma unroll
+                for (int u = 0; u < U4; ++u) {
+                    const int k = k0 + u * TPB;
+                    const bool in = k < n4;
+                    hv[u] = in ? h4[k] : z4; yv[u] = in ? y4[k] : z4; dv[u] = in ? d4[k] : z4;
+                    uv[u] = (in && u4) ? u4[k] : z4;
+                }
+#pragma unroll
+                for (int u = 0; u < U4; ++u) {
+                    const int k = k0 + u * TPB;
+                    if (k < n4) {
+                        const int r = k >> 4, q = k & 15;
+                        const float4 y = make_float4(yv[u].x - uv[u].x, yv[u].y - uv[u].y, yv[u].z - uv[u].z, yv[u].w - uv[u].w);
+                        const float4 d = dv[u];
+                        *reinterpret_cast<float4 *>(HW + (size_t)r * SP + 4 * q) = hv[u];
+                        *reinterpret_cast<float4 *>(DP + (size_t)r * SP + 4 * q) =
+                            make_float4(d.x * (1.0f - y.x * y.x), d.y * (1.0f - y.y * y.y), d.z * (1.0f - y.z * y.z), d.w * (1.0f - y.w * y.w));   // tanh'
+                    }
+                }
+            }
+            for (int k0 = tid; k0 < NN; k0 += 8 * TPB) {
+                float av[8], mv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int k = k0 + u * TPB;
+                    const bool in = k < NN;
+                    av[u] = in ? attn[base + k] : 0.0f;
+                    mv[u] = (in && adj) ? adj[base + k] : 1.0f;
+                    if (in && chan) mv[u] *= chan[(size_t)s * ch_stride + k];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int k = k0 + u * TPB;
+                    if (k < NN) {
+                        const int i = (int)(((float)k + 0.5f) * rcpN), j = k - i * N;  // exact for k < 2^22
+                        A[(size_t)i * SA + j] = av[u] * mv[u];
+                    }
+                }
+            }
         }
         __syncthreads();
-        for (int r = tid; r < N; r += TPB) {
+        for (int r = tid >> 4; r < N; r += TPB / 16) {                           // 16 lanes per row
             float *ar = A + (size_t)r * SA;
             float sum = 0.0f;
-            for (int j = 0; j < N; ++j) sum += ar[j];
-            const float dn = sum + 1e-12f;
-            den[r] = dn;
-            for (int j = 0; j < N; ++j) ar[j] = ar[j] / dn;
+            for (int j = tid & 15; j < N; j += 16) sum += ar[j];
+            const float dn = row_sum16(sum) + 1e-12f;
+            if ((tid & 15) == 0) den[r] = dn;
+            for (int j = tid & 15; j < N; j += 16) ar[j] = ar[j] / dn;
         }
         if (d_bias) for (int r = rg; r < N; r += TPB / 64) dbias_acc += DP[(size_t)r * SP + o];
         __syncthreads();
@@ -130,19 +164,29 @@ __global__ __launch_bounds__(TPB) void agg_bwd_kernel(int S, int N, const float 
                 }
 #pragma unroll
             for (int r = 0; r < 4; ++r) tt[r] = row_sum16(tt[r]);
+            float mk[MAXNT][4];
+#pragma unroll
+            for (int t = 0; t < MAXNT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * it + 4 * g + r, j = 16 * t + c;
+                    mk[t][r] = 1.0f;
+                    if (t < NT && i < N && j < N) {
+                        const size_t k = (size_t)i * N + j;
+                        if (adj) mk[t][r] = adj[base + k];
+                        if (chan) mk[t][r] *= chan[(size_t)s * ch_stride + k];
+                    }
+                }
+            float rden[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rden[r] = 1.0f / den[min(16 * it + 4 * g + r, NP - 1)];
 #pragma unroll
             for (int t = 0; t < MAXNT; ++t)
                 if (t < NT) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int i = 16 * it + 4 * g + r, j = 16 * t + c;
-                        if (i < N && j < N) {
-                            const size_t k = (size_t)i * N + j;
-                            float m = 1.0f;
-                            if (adj) m *= adj[base + k];
-                            if (chan) m *= chan[(size_t)s * ch_stride + k];
-                            d_attn[base + k] = m * (acc[t][r] - tt[r]) * (1.0f / den[i]);
-                        }
+                        if (i < N && j < N) d_attn[base + (size_t)i * N + j] = mk[t][r] * (acc[t][r] - tt[r]) * rden[r];
                     }
                 }
         }
@@ -177,18 +221,38 @@ __global__ __launch_bounds__(TPB) void attn_bwd_kernel(int S, int N, const float
     __syncthreads();
     for (int s = blockIdx.x; s < S; s += gridDim.x) {
         const size_t base = (size_t)s * NN, row0 = (size_t)s * N * E;
-        for (int k = tid; k < N * (E / 4); k += TPB) {
-            const int r = k >> 4, x = k & 15;
-            *reinterpret_cast<float4 *>(Q + (size_t)r * SR + 4 * x) = *reinterpret_cast<const float4 *>(q + row0 + (size_t)r * E + 4 * x);
-            *reinterpret_cast<float4 *>(K + (size_t)r * SR + 4 * x) = *reinterpret_cast<const float4 *>(e + row0 + (size_t)r * E + 4 * x);
-        }
-        // softmax backward, 16 lanes per row
-        for (int r = tid >> 4; r < N; r += TPB / 16) {
-            const float *mr = m + base + (size_t)r * N, *dr = d_m + base + (size_t)r * N;
-            float t = 0.0f;
-            for (int j = c; j < N; j += 16) t = fmaf(dr[j], mr[j], t);
-            t = row_sum16(t);
-            for (int j = c; j < N; j += 16) DS[(size_t)r * SA + j] = mr[j] * (dr[j] - t);
+        {
+            const float4 *q4 = reinterpret_cast<const float4 *>(q + row0), *e4 = reinterpret_cast<const float4 *>(e + row0);
+            const int n4 = N * (E / 4);
+            constexpr int U4 = MAXNT <= 5 ? MAXNT : 4;
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k0 = tid; k0 < n4; k0 += U4 * TPB) {
+                float4 qv[U4], ev[U4];
+#pragma unroll
+                for (int u = 0; u < U4; ++u) { const int k = k0 + u * TPB; qv[u] = k < n4 ? q4[k] : z4; ev[u] = k < n4 ? e4[k] : z4; }
+#pragma unroll
+                for (int u = 0; u < U4; ++u) {
+                    const int k = k0 + u * TPB;
+                    if (k < n4) {
+                        const int r = k >> 4, x = k & 15;
+                        *reinterpret_cast<float4 *>(Q + (size_t)r * SR + 4 * x) = qv[u];
+                        *reinterpret_cast<float4 *>(K + (size_t)r * SR + 4 * x) = ev[u];
+                    }
+                }
+            }
+            // softmax backward, 16 lanes per row, a row's (m, dm) pairs in registers (N <= 16 MAXNT: MAXNT per lane)
+            for (int r = tid >> 4; r < N; r += TPB / 16) {
+                const float *mr = m + base + (size_t)r * N, *dr = d_m + base + (size_t)r * N;
+                float mv[MAXNT], dv[MAXNT];
+#pragma unroll
+                for (int u = 0; u < MAXNT; ++u) { const int j = c + 16 * u; mv[u] = j < N ? mr[j] : 0.0f; dv[u] = j < N ? dr[j] : 0.0f; }
+                float t = 0.0f;
+#pragma unroll
+                for (int u = 0; u < MAXNT; ++u) t = fmaf(dv[u], mv[u], t);
+                t = row_sum16(t);
+#pragma unroll
+                for (int u = 0; u < MAXNT; ++u) { const int j = c + 16 * u; if (j < N) DS[(size_t)r * SA + j] = mv[u] * (dv[u] - t); }
+            }
         }
         __syncthreads();
         // this wave's 16 output features of both products, every row tile
