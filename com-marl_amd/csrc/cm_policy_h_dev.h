@@ -364,6 +364,17 @@ __device__ __forceinline__ void dump_f32(const float *src, int stride, float *__
     }
 }
 
+// H.Wg of the large-team path lives TRANSPOSED ([env][feature][source row] planes): row-major f32 [rows][64] to HBM
+template <int TPBW>
+__device__ __forceinline__ void dump_hwt(const h16 *hi, const h16 *lo, int kstride, int N, int rows, float *__restrict__ dst, size_t row0, int tid) {
+    if (!dst) return;
+    for (int k = tid; k < rows * EMB; k += TPBW) {
+        const int f = k & (EMB - 1), rj = k >> 6, e = rj / N, j = rj - e * N;
+        const size_t at = ((size_t)e * EMB + f) * kstride + j;
+        dst[(row0 + rj) * EMB + f] = join2(hi[at], lo[at]);
+    }
+}
+
 // ---- LDS map (bytes), shared by every path; regions that are never live together overlay each other -------------
 //   R1  planes 128 wide  : enc1 output, then the A tile of the aggregation (f32 [rows][NPA]), then head layer 1 output
 //   EP  planes 64 wide   : E
@@ -444,7 +455,7 @@ __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, c
     if (quad_path || big) l_enc2.template run<true, OUT_PLANES>(Ap, Ep, nullptr, 0, RT, wave, lane);
     else l_enc2.template run<true, OUT_PLANES | OUT_F32>(Ap, Ep, EF, SF, RT, wave, lane);
     const size_t grow0 = (size_t)s0 * N;                     // first global agent row of this workgroup
-    if (quad_path && sv_on) dump_planes<128, TPBW>(Ap, a.sv_a1, grow0, rows, tid);           // encoder hidden layer
+    if (sv_on) dump_planes<128, TPBW>(Ap, a.sv_a1, grow0, rows, tid);                        // encoder hidden layer
     LayerH<EMB, HEAD == 0 ? H1 : DH, NW> l_x1;               // first head layer (policy 64 -> 128, critic 64 -> 64)
     LayerH<H1, H2, NW> l_h2;
     if (quad_path) l_x1.load(HEAD == 0 ? ph.h1_p : chd.d1_p, HEAD == 0 ? ph.b1 : chd.b1, wave, lane);
@@ -559,6 +570,11 @@ __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, c
         if (L > 0) l_sq.load(tw.gcn_p, nullptr, wave, lane);
         lds_barrier();
         if (a.stop == 4) return;
+        if (sv_on) {                                             // E and Q are stable until the hops reuse T
+            dump_planes<64, TPBW>(Ep, a.sv_e, grow0, rows, tid);
+            if (big) dump_planes<64, TPBW>(Tp, a.sv_q, grow0, rows, tid);
+            else dump_f32<64, TPBW>(QF, SF, a.sv_q, grow0, rows, tid);
+        }
         if (big) {
             {   // scores on the f16 pipe: 16 x 16 tiles dealt round-robin to waves
                 const int c = lane & 15, g = lane >> 4, NT = (N + 15) >> 4, per_env = NT * NT;
@@ -702,6 +718,7 @@ __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, c
                 }
                 lds_barrier();
                 if (a.stop == 51 + l) return;
+                if (sv_on && l < 4) dump_hwt<TPBW>(hwt_hi, hwt_lo, kstride, N, rows, a.sv_hw[l], grow0, tid);
                 {   // D'[feature][row] = sum_k HWt[feature][k] A[row][k]: both operands are 8 consecutive k per lane (b128).
                     // Wave w owns features 16 (w & 3) .. +15; with 8 waves two waves share them and split the row tiles.
                     constexpr int MAXKB = (MAXMK == 25 || MAXMK == 15) ? 3 : 4;        // N <= 80 -> Kp <= 96; N <= 128 -> Kp <= 128
@@ -770,6 +787,7 @@ __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, c
                     }
                 }
                 lds_barrier();
+                if (sv_on && l < 4) dump_planes<64, TPBW>(Hp, a.sv_h[l], grow0, rows, tid);  // hop output (last: + residual)
                 continue;
             }
             // small teams (VALU): masked + renormalised rows of A, then A.(HW) per (row, feature)
@@ -806,6 +824,7 @@ __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, c
                 }
             }
             lds_barrier();
+            if (sv_on && l < 4) dump_f32<64, TPBW>(HW, SF, a.sv_hw[l], grow0, rows, tid);
             {
                 const int o = tid & (EMB - 1), rg = tid >> 6;
                 const float bvv = tw.gcn_b ? tw.gcn_b[(size_t)l * EMB + o] : 0.0f;
@@ -833,6 +852,7 @@ __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, c
                 }
             }
             lds_barrier();
+            if (sv_on && l < 4) dump_planes<64, TPBW>(Hp, a.sv_h[l], grow0, rows, tid);      // hop output (last: + residual)
         }
     }
     if (a.stop == 6) return;
@@ -869,13 +889,13 @@ __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, c
         l_x1.template run<true, OUT_PLANES>(Hp, Ap, nullptr, 0, RT, wave, lane);             // 64 -> 128 into R1
         lds_barrier();
         l_h2.template run<true, OUT_PLANES>(Ap, Tp, nullptr, 0, RT, wave, lane);             // 128 -> 64 into T
-        if (quad_path && sv_on) dump_planes<128, TPBW>(Ap, a.sv_x1, grow0, rows, tid);
+        if (sv_on) dump_planes<128, TPBW>(Ap, a.sv_x1, grow0, rows, tid);
         const int A = ph.n_act;
         LayerH<H3, 16, NW> l_h4;                             // 32 -> n_act (<= 8) logits, zero-padded to one feature tile
         l_h4.load(ph.h4_p, ph.b4, wave, lane, A);
         lds_barrier();
         l_h3.template run<true, OUT_PLANES>(Tp, Gp, nullptr, 0, RT, wave, lane);             // 64 -> 32 into EP
-        if (quad_path && sv_on) dump_planes<64, TPBW>(Tp, a.sv_x2, grow0, rows, tid);
+        if (sv_on) dump_planes<64, TPBW>(Tp, a.sv_x2, grow0, rows, tid);
         lds_barrier();
         if (a.stop == 7) return;
         // the sampler's uniforms do not depend on the logits: the last wave (idle in the 32 -> n_act layer unless the
@@ -888,9 +908,9 @@ __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, c
                 rs[r] = unit_f32(xr.x);
             }
         l_h4.template run<false, OUT_F32>(Gp, Gp, LG, SLG, RT, wave, lane);                  // logits f32 into T
-        if (quad_path && sv_on) dump_planes<32, TPBW>(Gp, a.sv_x3, grow0, rows, tid);
+        if (sv_on) dump_planes<32, TPBW>(Gp, a.sv_x3, grow0, rows, tid);
         lds_barrier();
-        if (quad_path && sv_on && a.sv_out)
+        if (sv_on && a.sv_out)
             for (int k = tid; k < rows * A; k += TPBW) { const int r = k / A, cc = k - r * A; a.sv_out[(grow0 + r) * A + cc] = LG[(size_t)r * SLG + cc]; }
         for (int r = tid; r < rows; r += TPBW) {
             float lg[MAX_ACT], p[MAX_ACT];
@@ -939,7 +959,7 @@ __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, c
         float *XF = reinterpret_cast<float *>(lds + lm.r1);                                  // critic: tanh(x1) f32 [rows][SF] in R1
         l_x1.template run<true, OUT_F32>(Hp, Hp, XF, SF, RT, wave, lane);
         lds_barrier();
-        if (quad_path && sv_on) dump_f32<64, TPBW>(XF, SF, a.sv_x1, grow0, rows, tid);
+        if (sv_on) dump_f32<64, TPBW>(XF, SF, a.sv_x1, grow0, rows, tid);
         {
             // value head 64 -> 1: eight lanes per row, eight features each (one thread per row left 7/8 of the workgroup
             // idle behind a 64-deep dependent chain of LDS reads)
@@ -958,7 +978,7 @@ __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, c
                 acc += chd.b2 ? chd.b2[0] : 0.0f;
                 if (part == 0 && r < rows) {
                     rs[r] = acc;
-                    if (quad_path && sv_on && a.sv_out) a.sv_out[grow0 + r] = acc;
+                    if (sv_on && a.sv_out) a.sv_out[grow0 + r] = acc;
                 }
             }
         }
@@ -968,6 +988,7 @@ __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, c
             for (int i = 0; i < N; ++i) v += rs[e * N + i];
             a.values[s0 + e] = v;
         }
+        store_attention();                                   // the training forward's backward reads it (cm_critic_forward_saved)
     }
 }
 

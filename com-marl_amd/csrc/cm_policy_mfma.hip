@@ -206,7 +206,7 @@ int critic_forward_mfma(const cm_critic_weights *w, int32_t S, const float *obs,
 
 }  // namespace cm
 
-static bool saved_shape_ok(int N, int L, int d) { return N == 4 && cm::mf::pick_epb(4) * 4 <= 32 && L <= 4 && L >= 0 && d <= 96; }
+static bool saved_shape_ok(int N, int L, int d) { return N >= 1 && N <= 128 && L <= 4 && L >= 0 && d <= 96; }
 static void set_saves(cm::mf::FwdArgs &a, const cm_fwd_saves *sv) {
     a.sv_on = 1;
     a.sv_a1 = sv->a1; a.sv_e = sv->e; a.sv_q = sv->q; a.sv_x1 = sv->x1; a.sv_x2 = sv->x2; a.sv_x3 = sv->x3; a.sv_out = sv->out;

@@ -220,7 +220,7 @@ int cm_critic_forward(const cm_critic_weights *w, int32_t n_samples, const float
  *   out         policy: logits [R, n_act] (before softmax / avail mask); critic: per-agent value [R] (before the sum)
  *   probs       policy only: the action probabilities [R, n_act] exactly as cm_policy_forward returns them (no avail mask)
  * attn [S,N,N] is written as in cm_policy_forward.  Returns 1 - nothing done - when there is no saved-forward
- * instantiation for the shape (built for teams of 4, n_hops <= 4, obs dim <= 96): the caller then runs layer by layer. */
+ * instantiation for the shape (teams of <= 128 agents, n_hops <= 4, obs dim <= 96): the caller then runs layer by layer. */
 typedef struct cm_fwd_saves {
     float *a1, *e, *q, *hw[4], *h[4], *x1, *x2, *x3, *out, *probs;
 } cm_fwd_saves;

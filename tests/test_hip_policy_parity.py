@@ -347,17 +347,19 @@ def test_operand_pack_path_equals_plain_weight_path(n_agents, d, torch_cuda):
     np.testing.assert_allclose(p2.cpu().numpy(), p_ref.cpu().numpy(), **TOL)
 
 
-@pytest.mark.parametrize("d,hops,residual,masks", [(21, 2, True, False), (21, 2, True, True), (53, 1, False, True), (77, 3, True, True),
-                                                  (29, 2, False, False)])
-def test_fused_training_path_vs_per_layer_autograd(d, hops, residual, masks, torch_cuda, monkeypatch):
-    """Teams of 4: the whole-network training path (ONE forward launch that stores the activations, cm_*_forward_saved, +
+@pytest.mark.parametrize("d,hops,residual,masks,N", [(21, 2, True, False, 4), (21, 2, True, True, 4), (53, 1, False, True, 4), (77, 3, True, True, 4),
+                                                    (29, 2, False, False, 4), (21, 2, True, True, 6), (29, 2, False, True, 3),
+                                                    (77, 2, True, True, 24), (53, 2, True, True, 72), (77, 1, False, False, 54),
+                                                    (21, 2, True, True, 16), (40, 3, True, True, 80)])
+def test_fused_training_path_vs_per_layer_autograd(d, hops, residual, masks, N, torch_cuda, monkeypatch):
+    """Every team size: the whole-network training path (ONE forward launch that stores the activations, cm_*_forward_saved, +
     the hand-written backward chain of nets._FusedNetFn) against the per-layer autograd path of the same nets
     (COMMARL_FUSED_TRAIN=0): policy probabilities / critic values 1e-5, every parameter gradient to 1e-4 relative + 1e-5
     of the tensor's largest entry (the two forwards differ in the last bits: f16-split MFMA vs f32 MFMA per layer)."""
     torch = torch_cuda
     from com_marl_amd import nets
     from com_marl_amd.envs import EnvSpec, _Box, _Discrete
-    N, P, T = 4, 7, 13                                     # 91 samples: ragged last workgroup (8 envs per workgroup)
+    P, T = (7, 13) if N <= 24 else (3, 5)                  # 91 samples: ragged last workgroup (8 envs per workgroup at N = 4)
     spec = EnvSpec(_Box(np.zeros(N * d), np.ones(N * d)), _Discrete(5))
     torch.manual_seed(d + hops)
     pol = nets.CommCategoricalMLPPolicy(spec, n_agents=N, n_gcn_layers=hops, residual=residual, device="cuda:0")
@@ -405,7 +407,7 @@ def test_fused_training_path_vs_per_layer_autograd(d, hops, residual, masks, tor
 def test_evaluate_nograd_shares_one_forward(torch_cuda):
     """policy.evaluate_nograd (ONE launch giving logits and action probabilities: what train_once shares between the
     loss, the old log-likelihood and the KL / entropy diagnostics) returns the probabilities of act_device bit for bit
-    and logits whose softmax they are; shapes without a fused training forward fall back to act_device."""
+    and logits whose softmax they are, for teams of 4 (register path) and other sizes alike."""
     torch = torch_cuda
     from com_marl_amd import nets
     from com_marl_amd.envs import EnvSpec, _Box, _Discrete
@@ -422,8 +424,5 @@ def test_evaluate_nograd_shares_one_forward(torch_cuda):
                                    ch.reshape(P * T, 2, n_agents, n_agents), want_actions=False, want_attn=False, policy_step=0)
         assert probs.shape == (P, T, n_agents, 5)
         assert torch.equal(probs.reshape(P * T, n_agents, 5), ref)
-        if n_agents == 4:
-            assert logits is not None and logits.shape == (P, T, 4, 5)
-            np.testing.assert_allclose(torch.softmax(logits, -1).cpu().numpy(), probs.cpu().numpy(), rtol=1e-5, atol=1e-6)
-        else:
-            assert logits is None
+        assert logits is not None and logits.shape == (P, T, n_agents, 5)
+        np.testing.assert_allclose(torch.softmax(logits, -1).cpu().numpy(), probs.cpu().numpy(), rtol=1e-5, atol=1e-6)
