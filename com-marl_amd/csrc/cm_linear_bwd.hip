@@ -60,6 +60,28 @@ __device__ __forceinline__ void issue_tile(unsigned lds_addr, const float *__res
     }
 }
 
+// First-layer form: the source rows are KR < W floats wide (the observation: 21 / 29 / 53 / 77) and only 4-byte aligned.
+// One dword per lane (256 bytes per wave-instruction); tile columns >= KR are fetched from a zero word.
+__device__ float zero_word[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+
+template <int W>
+__device__ __forceinline__ void issue_tile_ragged(unsigned lds_addr, const float *__restrict__ src, long r0, int rows, int KR, int wave,
+                                                  int lane) {
+    constexpr int NI = W / 8;                              // ROWS * W dwords / 64 lanes / 8 waves
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int inst = wave * NI + i, p = inst * 64 + lane;
+        const int r = p / W, cw = p % W, slot = cw >> 2, w = cw & 3;
+        const int rr = r < rows ? r : rows - 1;
+        const int col = 4 * (slot ^ swz<W>(r)) + w;
+        const float *g = col < KR ? src + (r0 + rr) * KR + col : zero_word;
+        const unsigned dst_b = __builtin_amdgcn_readfirstlane(lds_addr + (unsigned)(inst * 256));
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(g), "s"(dst_b) : "memory");
+    }
+}
+
 // column of element c of permuted tile u of a W-wide operand
 template <int W>
 __device__ __forceinline__ int col_of(int u, int c) { return W == 32 ? 2 * c + u : 64 * (u >> 2) + 4 * c + (u & 3); }
@@ -91,8 +113,9 @@ __device__ __forceinline__ void load_cols(const float *tile, int r, int c, int u
     }
 }
 
-template <int KT, int OT, int ACT, int LAYOUT>
-__global__ __launch_bounds__(TPB) void bwd_kernel(long R, const float *__restrict__ X, const float *__restrict__ W,
+// RAG: first-layer form - x rows are KR <= K floats wide (zero-padded to K in LDS), no input gradient, dW is [O][KR]
+template <int KT, int OT, int ACT, int LAYOUT, bool RAG = false>
+__global__ __launch_bounds__(TPB) void bwd_kernel(long R, int KR, const float *__restrict__ X, const float *__restrict__ W,
                                                   const float *__restrict__ DY, const float *__restrict__ DY2,
                                                   const float *__restrict__ Yv,
                                                   float *__restrict__ DX, float *__restrict__ DW, float *__restrict__ DB) {
@@ -118,8 +141,8 @@ __global__ __launch_bounds__(TPB) void bwd_kernel(long R, const float *__restric
     for (float &z : zsum) z = 0.0f;
 
     // dx: row tile rg, input-feature tiles kt = hb * NKT + i; wf[i][4 oq + u] = W(k = 16 kt + c, o = 16 oq + 4 g + u)
-    float wf[NKT][4 * OT];
-    if (DX) {
+    float wf[RAG ? 1 : NKT][RAG ? 1 : 4 * OT];
+    if constexpr (!RAG) if (DX) {
 #pragma unroll
         for (int i = 0; i < NKT; ++i) {
             const int k = 16 * (hb * NKT + i) + c;
@@ -164,7 +187,8 @@ __global__ __launch_bounds__(TPB) void bwd_kernel(long R, const float *__restric
         const int rows = (int)min((long)ROWS, R - r0);
         const unsigned b = lds_base + (unsigned)((buf - lds) * sizeof(float));
         issue_tile<O>(b, DY, r0, rows, wave, lane);
-        issue_tile<K>(b + ZF * (unsigned)sizeof(float), X, r0, rows, wave, lane);
+        if constexpr (RAG) issue_tile_ragged<K>(b + ZF * (unsigned)sizeof(float), X, r0, rows, KR, wave, lane);
+        else issue_tile<K>(b + ZF * (unsigned)sizeof(float), X, r0, rows, wave, lane);
         if (ACT) issue_tile<O>(lds_base + 2 * BUF * (unsigned)sizeof(float), Yv, r0, rows, wave, lane);
         if (DY2) issue_tile<O>(lds_base + (2 * BUF + (ACT ? ZF : 0)) * (unsigned)sizeof(float), DY2, r0, rows, wave, lane);
     };
@@ -208,7 +232,7 @@ __global__ __launch_bounds__(TPB) void bwd_kernel(long R, const float *__restric
             }
         }
         // ---- input gradient, transposed: D[k][row] = sum_o W(k, o) dz[row][o] ----
-        if (DX) {
+        if constexpr (!RAG) if (DX) {
             v4f d[NKT];
 #pragma unroll
             for (int i = 0; i < NKT; ++i) d[i] = (v4f){ 0.f, 0.f, 0.f, 0.f };
@@ -270,7 +294,8 @@ __global__ __launch_bounds__(TPB) void bwd_kernel(long R, const float *__restric
             const int cbq = col_of<WB>(ub, lc);
             const float sv[4] = { s.x, s.y, s.z, s.w };
 #pragma unroll
-            for (int r = 0; r < 4; ++r) atomicAdd(DW + (size_t)col_of<WA>(ua, 4 * lg + r) * WB + cbq, sv[r]);
+            for (int r = 0; r < 4; ++r)
+                if (!RAG || cbq < KR) atomicAdd(DW + (size_t)col_of<WA>(ua, 4 * lg + r) * (RAG ? KR : WB) + cbq, sv[r]);
         }
     }
     if (DB) {
@@ -305,22 +330,22 @@ __global__ __launch_bounds__(TPB) void bwd_kernel(long R, const float *__restric
     }
 }
 
-template <int KT, int OT, int ACT, int LAYOUT>
-static int launch(long R, const float *x, const float *w, const float *dy, const float *dy2, const float *y, float *dx, float *dw, float *db,
+template <int KT, int OT, int ACT, int LAYOUT, bool RAG = false>
+static int launch(long R, int KR, const float *x, const float *w, const float *dy, const float *dy2, const float *y, float *dx, float *dw, float *db,
                   hipStream_t st) {
     constexpr int K = 16 * KT, O = 16 * OT;
     const size_t lds = ((size_t)2 * ROWS * (K + O) + (ACT ? (size_t)ROWS * O : 0) + (dy2 ? (size_t)ROWS * O : 0)) * sizeof(float);
     if (lds > 160 * 1024) return 1;
     static bool attr = false;
     if (!attr) {
-        CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bwd_kernel<KT, OT, ACT, LAYOUT>),
+        CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bwd_kernel<KT, OT, ACT, LAYOUT, RAG>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
     static const int n_cu = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
     const long chunks = (R + ROWS - 1) / ROWS;
     const int blocks = (int)std::min<long>(chunks, n_cu);
-    hipLaunchKernelGGL((bwd_kernel<KT, OT, ACT, LAYOUT>), dim3(blocks), dim3(TPB), std::max<size_t>(lds, 33 * 1024), st, R, x, w, dy, dy2, y, dx, dw, db);
+    hipLaunchKernelGGL((bwd_kernel<KT, OT, ACT, LAYOUT, RAG>), dim3(blocks), dim3(TPB), std::max<size_t>(lds, 33 * 1024), st, R, KR, x, w, dy, dy2, y, dx, dw, db);
     CM_HIP(hipGetLastError());
     return CM_OK;
 }
@@ -333,12 +358,30 @@ int linear_bwd_stream(long R, int K, int O, const float *x, const float *w, int 
     static const bool off = [] { const char *e = getenv("COMMARL_LIN_BWD"); return e && e[0] == 'o'; }();   // "old"
     if (off) return 1;
     const auto ok_w = [](int v) { return v == 32 || v == 64 || v == 128; };
+    const hipStream_t st = (hipStream_t)stream;
+    if (!ok_w(K) && ok_w(O) && K <= 128 && !dx && layout == 0 && !(((uintptr_t)dy | (uintptr_t)dy2 | (uintptr_t)y) & 15) && !((uintptr_t)x & 3)) {
+        // first layer (observation -> hidden): ragged input rows, no input gradient
+#define CM_RG(KT_, OT_) (y ? lin2::launch<KT_, OT_, 1, 0, true>(R, K, x, w, dy, dy2, y, dx, dw, db, st) : lin2::launch<KT_, OT_, 0, 0, true>(R, K, x, w, dy, dy2, y, dx, dw, db, st))
+        const int kt = K <= 32 ? 2 : (K <= 64 ? 4 : 8);
+        switch (kt * 1000 + O) {
+        case 2032: return CM_RG(2, 2);
+        case 2064: return CM_RG(2, 4);
+        case 2128: return CM_RG(2, 8);
+        case 4032: return CM_RG(4, 2);
+        case 4064: return CM_RG(4, 4);
+        case 4128: return CM_RG(4, 8);
+        case 8032: return CM_RG(8, 2);
+        case 8064: return CM_RG(8, 4);
+        case 8128: return CM_RG(8, 8);
+        default: return 1;
+        }
+#undef CM_RG
+    }
     if (!ok_w(K) || !ok_w(O) || (K == 128 && O == 128)) return 1;
     const uintptr_t al = (uintptr_t)x | (uintptr_t)dy | (uintptr_t)dy2 | (uintptr_t)y | (uintptr_t)dx;
     if (al & 15) return 1;
     if (layout == 1 && !(K == 64 && O == 64)) return 1;   // the [in][out] weights are the 64 x 64 graph-convolution ones
-    const hipStream_t st = (hipStream_t)stream;
-#define CM_B2(KT_, OT_, L_) (y ? lin2::launch<KT_, OT_, 1, L_>(R, x, w, dy, dy2, y, dx, dw, db, st) : lin2::launch<KT_, OT_, 0, L_>(R, x, w, dy, dy2, y, dx, dw, db, st))
+#define CM_B2(KT_, OT_, L_) (y ? lin2::launch<KT_, OT_, 1, L_>(R, K, x, w, dy, dy2, y, dx, dw, db, st) : lin2::launch<KT_, OT_, 0, L_>(R, K, x, w, dy, dy2, y, dx, dw, db, st))
     if (layout == 1) return CM_B2(4, 4, 1);
     switch (K * 1000 + O) {
     case 32032: return CM_B2(2, 2, 0);

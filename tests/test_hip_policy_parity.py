@@ -236,7 +236,8 @@ def test_linear_weight_gradient_kernel(R, IN, OUT, torch_cuda):
                                                   (333, 64, 128, 1, 0), (5000, 32, 5, 0, 0), (129, 64, 1, 0, 0),
                                                   (64, 77, 128, 1, 0), (100000, 128, 128, 1, 0), (63, 64, 64, 0, 0),
                                                   (300001, 64, 32, 1, 0), (20000, 32, 64, 1, 0), (20001, 32, 32, 0, 0), (12345, 32, 128, 1, 0),
-                                                  (5000, 128, 32, 0, 0), (40961, 64, 64, 1, 1), (16447, 64, 128, 0, 0)])
+                                                  (5000, 128, 32, 0, 0), (40961, 64, 64, 1, 1), (16447, 64, 128, 0, 0), (30001, 53, 128, 1, 0), (5000, 29, 64, 0, 0),
+                                                  (70003, 77, 128, 1, 0), (129, 21, 32, 1, 0)])
 def test_fused_linear_act_kernels(R, IN, OUT, act, layout, torch_cuda):
     """cm_linear_act_forward / backward (one HBM pass each: y = act(x W^T + b); dx, dW, db from dy, y, x) against an f64
     torch reference of the same layer - forward and every gradient, both weight layouts, ragged last chunks.
