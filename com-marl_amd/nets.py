@@ -273,7 +273,7 @@ def masked_aggregate(attn, dist_adj, channels, hop, hw, bias):
 
 
 # ---------------------------------------------------------------------------------------------
-# whole-network training forward (teams of 4): ONE fused launch that stores what the backward needs, and a hand-written
+# whole-network training forward (every team size <= 128): ONE fused launch that stores what the backward needs, and a hand-written
 # backward chain over the C-ABI kernels - no per-layer forward kernels, no gradient-accumulation adds from autograd
 # ---------------------------------------------------------------------------------------------
 def _lin_bwd(x2, w, layout, dy2, y2, want_dx, has_bias, dy_add=None):
