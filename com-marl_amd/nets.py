@@ -291,7 +291,9 @@ def _lin_bwd(x2, w, layout, dy2, y2, want_dx, has_bias, dy_add=None):
 
 
 def _fused_train_ok(net, obs):
-    return (obs.is_cuda and torch.is_grad_enabled() and 1 <= net._n_agents <= 128 and 1 <= len(net.gcn_layers) <= 4
+    # teams above 80 agents exceed the f16-split forward's LDS budget (its activation planes + the N x N score matrix):
+    # they keep the per-layer path
+    return (obs.is_cuda and torch.is_grad_enabled() and 1 <= net._n_agents <= 80 and 1 <= len(net.gcn_layers) <= 4
             and net._dec_obs_dim <= 96 and len(net.encoder._layers) == 1
             and os.environ.get("COMMARL_FUSED_TRAIN", "1") != "0" and os.environ.get("COMMARL_POLICY_KERNEL", "")[:1] not in ("f", "v"))
 

@@ -351,7 +351,8 @@ def test_operand_pack_path_equals_plain_weight_path(n_agents, d, torch_cuda):
 @pytest.mark.parametrize("d,hops,residual,masks,N", [(21, 2, True, False, 4), (21, 2, True, True, 4), (53, 1, False, True, 4), (77, 3, True, True, 4),
                                                     (29, 2, False, False, 4), (21, 2, True, True, 6), (29, 2, False, True, 3),
                                                     (77, 2, True, True, 24), (53, 2, True, True, 72), (77, 1, False, False, 54),
-                                                    (21, 2, True, True, 16), (40, 3, True, True, 80)])
+                                                    (21, 2, True, True, 16), (40, 3, True, True, 80), (29, 2, True, True, 12), (21, 1, True, True, 9),
+                                                    (21, 2, True, False, 96)])
 def test_fused_training_path_vs_per_layer_autograd(d, hops, residual, masks, N, torch_cuda, monkeypatch):
     """Every team size: the whole-network training path (ONE forward launch that stores the activations, cm_*_forward_saved, +
     the hand-written backward chain of nets._FusedNetFn) against the per-layer autograd path of the same nets
@@ -360,7 +361,7 @@ def test_fused_training_path_vs_per_layer_autograd(d, hops, residual, masks, N, 
     torch = torch_cuda
     from com_marl_amd import nets
     from com_marl_amd.envs import EnvSpec, _Box, _Discrete
-    P, T = (7, 13) if N <= 24 else (3, 5)                  # 91 samples: ragged last workgroup (8 envs per workgroup at N = 4)
+    P, T = (7, 13) if N <= 24 else (3, 5)                  # (N = 96: above the fused path's limit -> both modes run per layer)
     spec = EnvSpec(_Box(np.zeros(N * d), np.ones(N * d)), _Discrete(5))
     torch.manual_seed(d + hops)
     pol = nets.CommCategoricalMLPPolicy(spec, n_agents=N, n_gcn_layers=hops, residual=residual, device="cuda:0")
