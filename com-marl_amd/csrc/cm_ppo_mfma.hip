@@ -89,10 +89,11 @@ __global__ __launch_bounds__(TPB) void agg_bwd_kernel(int S, int N, const float 
                     }
                 }
             }
-            for (int k0 = tid; k0 < NN; k0 += 8 * TPB) {
-                float av[8], mv[8];
+            constexpr int UA = MAXNT <= 5 ? MAXNT * MAXNT : 16;                   // N^2 / 256 <= MAXNT^2: one batch up to N = 80
+            for (int k0 = tid; k0 < NN; k0 += UA * TPB) {
+                float av[UA], mv[UA];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < UA; ++u) {
                     const int k = k0 + u * TPB;
                     const bool in = k < NN;
                     av[u] = in ? attn[base + k] : 0.0f;
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(TPB) void agg_bwd_kernel(int S, int N, const float 
                     if (in && chan) mv[u] *= chan[(size_t)s * ch_stride + k];
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < UA; ++u) {
                     const int k = k0 + u * TPB;
                     if (k < NN) {
                         const int i = (int)(((float)k + 0.5f) * rcpN), j = k - i * N;  // exact for k < 2^22
@@ -145,6 +146,20 @@ __global__ __launch_bounds__(TPB) void agg_bwd_kernel(int S, int N, const float 
         // ---- dA = dP . hw^T, one row tile per wave at a time; through the renormalisation in registers:
         //      dM_ij = mask_ij (dA_ij - sum_k dA_ik A_ik) / den_i ----
         for (int it = wave; it < NT; it += TPB / 64) {
+            // the epilogue's mask values: requested before the products, consumed after them
+            float mk[MAXNT][4];
+#pragma unroll
+            for (int t = 0; t < MAXNT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * it + 4 * g + r, j = 16 * t + c;
+                    mk[t][r] = 1.0f;
+                    if (t < NT && i < N && j < N) {
+                        const size_t k = (size_t)i * N + j;
+                        if (adj) mk[t][r] = adj[base + k];
+                        if (chan) mk[t][r] *= chan[(size_t)s * ch_stride + k];
+                    }
+                }
             v4f acc[MAXNT];
 #pragma unroll
             for (int t = 0; t < MAXNT; ++t) acc[t] = (v4f){ 0.f, 0.f, 0.f, 0.f };
@@ -164,19 +179,6 @@ __global__ __launch_bounds__(TPB) void agg_bwd_kernel(int S, int N, const float 
                 }
 #pragma unroll
             for (int r = 0; r < 4; ++r) tt[r] = row_sum16(tt[r]);
-            float mk[MAXNT][4];
-#pragma unroll
-            for (int t = 0; t < MAXNT; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = 16 * it + 4 * g + r, j = 16 * t + c;
-                    mk[t][r] = 1.0f;
-                    if (t < NT && i < N && j < N) {
-                        const size_t k = (size_t)i * N + j;
-                        if (adj) mk[t][r] = adj[base + k];
-                        if (chan) mk[t][r] *= chan[(size_t)s * ch_stride + k];
-                    }
-                }
             float rden[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) rden[r] = 1.0f / den[min(16 * it + 4 * g + r, NP - 1)];
@@ -240,18 +242,30 @@ __global__ __launch_bounds__(TPB) void attn_bwd_kernel(int S, int N, const float
                     }
                 }
             }
-            // softmax backward, 16 lanes per row, a row's (m, dm) pairs in registers (N <= 16 MAXNT: MAXNT per lane)
-            for (int r = tid >> 4; r < N; r += TPB / 16) {
-                const float *mr = m + base + (size_t)r * N, *dr = d_m + base + (size_t)r * N;
-                float mv[MAXNT], dv[MAXNT];
+            // softmax backward, 16 lanes per row, (m, dm) in registers; up to N = 80 every row of a lane group is requested in
+            // ONE batch (MAXNT rows x MAXNT columns per lane) instead of one HBM round trip per row
+            constexpr int RB = MAXNT <= 5 ? MAXNT : 1;
+            for (int rb = tid >> 4; rb < N; rb += RB * (TPB / 16)) {
+                float mv[RB][MAXNT], dv[RB][MAXNT];
 #pragma unroll
-                for (int u = 0; u < MAXNT; ++u) { const int j = c + 16 * u; mv[u] = j < N ? mr[j] : 0.0f; dv[u] = j < N ? dr[j] : 0.0f; }
-                float t = 0.0f;
+                for (int ri = 0; ri < RB; ++ri) {
+                    const int r = rb + ri * (TPB / 16);
+                    const float *mr = m + base + (size_t)min(r, N - 1) * N, *dr = d_m + base + (size_t)min(r, N - 1) * N;
 #pragma unroll
-                for (int u = 0; u < MAXNT; ++u) t = fmaf(dv[u], mv[u], t);
-                t = row_sum16(t);
+                    for (int u = 0; u < MAXNT; ++u) { const int j = c + 16 * u; const bool in = r < N && j < N; mv[ri][u] = in ? mr[j] : 0.0f; dv[ri][u] = in ? dr[j] : 0.0f; }
+                }
 #pragma unroll
-                for (int u = 0; u < MAXNT; ++u) { const int j = c + 16 * u; if (j < N) DS[(size_t)r * SA + j] = mv[u] * (dv[u] - t); }
+                for (int ri = 0; ri < RB; ++ri) {
+                    const int r = rb + ri * (TPB / 16);
+                    float t = 0.0f;
+#pragma unroll
+                    for (int u = 0; u < MAXNT; ++u) t = fmaf(dv[ri][u], mv[ri][u], t);
+                    t = row_sum16(t);
+                    if (r < N) {
+#pragma unroll
+                        for (int u = 0; u < MAXNT; ++u) { const int j = c + 16 * u; if (j < N) DS[(size_t)r * SA + j] = mv[ri][u] * (dv[ri][u] - t); }
+                    }
+                }
             }
         }
         __syncthreads();
@@ -259,6 +273,19 @@ __global__ __launch_bounds__(TPB) void attn_bwd_kernel(int S, int N, const float
         v4f aq[MAXNT], ae[MAXNT];
 #pragma unroll
         for (int t = 0; t < MAXNT; ++t) { aq[t] = (v4f){ 0.f, 0.f, 0.f, 0.f }; ae[t] = aq[t]; }
+        float adv[MAXNT][4];                                                       // the addends of d_e: requested before the products
+#pragma unroll
+        for (int t = 0; t < MAXNT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * t + 4 * g + r;
+                adv[t][r] = 0.0f;
+                if (t < NT && row < N) {
+                    const size_t at = row0 + (size_t)row * E + 16 * wave + c;
+                    if (add0) adv[t][r] = add0[at];
+                    if (add1) adv[t][r] += add1[at];
+                }
+            }
         for (int kk = 0; kk < NP / 4; ++kk) {
             const float be = K[(size_t)(4 * kk + g) * SR + 16 * wave + c];        // e[j = 4 kk + g]
             const float bq = Q[(size_t)(4 * kk + g) * SR + 16 * wave + c];        // q[i = 4 kk + g]
@@ -280,10 +307,7 @@ __global__ __launch_bounds__(TPB) void attn_bwd_kernel(int S, int N, const float
                     if (row < N) {
                         const size_t at = row0 + (size_t)row * E + 16 * wave + c;
                         d_q[at] = aq[t][r];
-                        float v = ae[t][r];
-                        if (add0) v += add0[at];
-                        if (add1) v += add1[at];
-                        d_e[at] = v;
+                        d_e[at] = ae[t][r] + adv[t][r];
                     }
                 }
             }
