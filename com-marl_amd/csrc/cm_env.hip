@@ -190,7 +190,7 @@ extern "C" int cm_env_create(const cm_env_cfg *cfg, cm_env_t *out) {
     if (e != hipSuccess) { delete h; return hip_fail(e, "hipMalloc(env arena)"); }
     char *base = (char *)h->arena;
     e = hipMemset(base, 0, off);
-    if (e != hipSuccess) { hipFree(h->arena); delete h; return hip_fail(e, "hipMemset"); }
+    if (e != hipSuccess) { (void)hipFree(h->arena); delete h; return hip_fail(e, "hipMemset"); }
     d.agent_pos = (int2 *)(base + o_ap); d.prey_pos = (int2 *)(base + o_pp); d.alive = (uint8_t *)(base + o_al);
     d.visited = (uint32_t *)(base + o_vis); d.step_count = (int32_t *)(base + o_sc); d.total_capture = (int32_t *)(base + o_tc);
     d.success = (int32_t *)(base + o_su); d.ge_state = (uint8_t *)(base + o_ge); d.rng_step = (uint32_t *)(base + o_rs);
@@ -206,14 +206,14 @@ extern "C" int cm_env_create(const cm_env_cfg *cfg, cm_env_t *out) {
                            { o_ls, lut_step.data(), (size_t)(c.max_steps + 1) * 4, "step LUT" } };
         for (const Up &u : ups) {
             e = hipMemcpy(base + u.off, u.src, u.bytes, hipMemcpyHostToDevice);
-            if (e != hipSuccess) { hipFree(h->arena); delete h; return hip_fail(e, u.what); }
+            if (e != hipSuccess) { (void)hipFree(h->arena); delete h; return hip_fail(e, u.what); }
         }
         if (c.channel == CM_CH_GE) {
             e = hipMemset(base + o_ge, 1, B * N * N);
-            if (e != hipSuccess) { hipFree(h->arena); delete h; return hip_fail(e, "hipMemset(GE state)"); }
+            if (e != hipSuccess) { (void)hipFree(h->arena); delete h; return hip_fail(e, "hipMemset(GE state)"); }
         }
         e = hipMemset(base + o_ac, 1, B * N);                            // agent_condition = ones (predator_prey.py:74)
-        if (e != hipSuccess) { hipFree(h->arena); delete h; return hip_fail(e, "hipMemset(agent condition)"); }
+        if (e != hipSuccess) { (void)hipFree(h->arena); delete h; return hip_fail(e, "hipMemset(agent condition)"); }
     }
     d.lds_env = lds_env_bytes(S, c.n_agents, M ? M : 1);
     {   // lanes per env: the smallest sub-wave group that still gives every agent / prey its own lane
@@ -229,7 +229,7 @@ extern "C" int cm_env_create(const cm_env_cfg *cfg, cm_env_t *out) {
     d.rcp_d = 1.0f / (float)d.d; d.rcp_W = 1.0f / (float)d.W; d.rcp_N = 1.0f / (float)d.N;
     d.rcp_WW = 1.0f / (float)(d.W * d.W); d.rcp_NN = 1.0f / (float)(d.N * d.N);
     e = hipDeviceSynchronize();
-    if (e != hipSuccess) { hipFree(h->arena); delete h; return hip_fail(e, "cm_env_create sync"); }
+    if (e != hipSuccess) { (void)hipFree(h->arena); delete h; return hip_fail(e, "cm_env_create sync"); }
     *out = h;
     return CM_OK;
 }

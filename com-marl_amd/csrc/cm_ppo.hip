@@ -230,7 +230,7 @@ __global__ __launch_bounds__(TPB) void attn_bwd_kernel(int S, int N, int EPB, co
                                                       float *__restrict__ d_e) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int SE = E + 4;
-    const int tid = threadIdx.x, NN = N * N, NP = N | 1, rows_max = EPB * N;
+    const int tid = threadIdx.x, NP = N | 1, rows_max = EPB * N;
     float *Q = lds, *K = Q + (size_t)rows_max * SE, *DS = K + (size_t)rows_max * SE;
     for (int s0 = blockIdx.x * EPB; s0 < S; s0 += gridDim.x * EPB) {
         const int envs = min(EPB, S - s0), rows = envs * N;
