@@ -1,5 +1,5 @@
 """End-to-end sanity: a few dozen PPO epochs on the headline env (device sampler + CentralizedMAPPO.train_once with every fused
-path on) - the average return and capture count should climb.  python tools/learn_check.py [epochs] [envs]"""
+path on) - the average return and capture count should climb.  python tools/learn_check.py [epochs] [envs] [config]"""
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np, torch
@@ -10,7 +10,7 @@ from com_marl_amd.sampler import CentralizedMAOnPolicyVectorizedSampler
 
 epochs = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
-cfg = dict(bench.CONFIGS["pp_map10"])
+cfg = dict(bench.CONFIGS[sys.argv[3] if len(sys.argv) > 3 else "pp_map10"])
 dev = torch.device("cuda:0")
 env = E.GridEnvBatch(cfg["scenario"], bench.env_params(cfg), B, device=dev, seed=1)
 spec = E.EnvSpec(E._Box(np.zeros(env.d * env.N), np.ones(env.d * env.N)), E._Discrete(5))
@@ -34,5 +34,5 @@ for ep in range(epochs):
     paths = smp.obtain_samples(ep, batch_size=B * env.N * mpl)
     algo.train_once(itr=ep, paths=paths)
     s = algo.stats
-    print(f"epoch {ep:3d}  return {s['AverageReturn']:8.2f}  captures {s['AverageCaptureCount']:5.2f}  success {s['SuccessRate']:.3f}  "
+    print(f"epoch {ep:3d}  return {s['AverageReturn']:8.2f}  captures {s['AverageCaptureCount']:6.2f}  success {s['SuccessRate']:.3f}  "
           f"steps {s['AverageStepCount']:6.1f}  kl {s['KL']:.2e}  entropy {s['Entropy']:.3f}  ({time.time() - t0:.0f} s)", flush=True)
