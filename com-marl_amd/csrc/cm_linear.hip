@@ -282,6 +282,8 @@ __global__ __launch_bounds__(TPB, (MAXT == 8 ? 2 : 1)) void bwd_kernel(long R, i
 namespace cm {
 int linear_bwd_stream(long R, int K, int O, const float *x, const float *w, int layout, const float *dy, const float *dy2,
                       const float *y, float *dx, float *dw, float *db, void *stream);   // cm_linear_bwd.hip: widths 32 / 64 / 128
+int encoder_bwd_chain(long R, int d, const float *obs, const float *a1, const float *e, const float *w2, const float *dy, const float *dy2,
+                      float *dw2, float *db2, float *dw1, float *db1, void *stream);
 }
 using namespace cm;
 
@@ -330,4 +332,11 @@ extern "C" int cm_linear_act_backward(int64_t R, int32_t K, int32_t O, const flo
 #undef CM_LB
     CM_HIP(hipGetLastError());
     return CM_OK;
+}
+
+extern "C" int cm_encoder_backward(int64_t R, int32_t d, const float *obs, const float *a1, const float *e, const float *w2, const float *dy,
+                                   const float *dy2, float *dw2, float *db2, float *dw1, float *db1, void *stream) {
+    if (!obs || !a1 || !e || !w2 || !dy || !dw2 || !dw1) return set_error(CM_ERR_ARG, "cm_encoder_backward: null argument");
+    if (R <= 0) return CM_OK;
+    return encoder_bwd_chain(R, d, obs, a1, e, w2, dy, dy2, dw2, db2, dw1, db1, stream);
 }

@@ -114,13 +114,20 @@ __device__ __forceinline__ void load_cols(const float *tile, int r, int c, int u
 }
 
 // RAG: first-layer form - x rows are KR <= K floats wide (zero-padded to K in LDS), no input gradient, dW is [O][KR]
-template <int KT, int OT, int ACT, int LAYOUT, bool RAG = false>
+// WO > 0: two chained layers (the encoder: obs -> x = tanh(.) -> y = tanh(.)).  The input gradient of this layer never
+// leaves the workgroup: multiplied by tanh'(x) it overwrites the x tile IN PLACE (every position is produced by exactly one
+// lane) and feeds the FIRST layer's weight / bias gradient against a WO-wide observation tile (rows KO <= WO floats wide):
+// DW1 [K][KO], DB1 [K]; DX is not written.
+template <int KT, int OT, int ACT, int LAYOUT, bool RAG = false, int WO = 0>
 __global__ __launch_bounds__(TPB) void bwd_kernel(long R, int KR, const float *__restrict__ X, const float *__restrict__ W,
                                                   const float *__restrict__ DY, const float *__restrict__ DY2,
                                                   const float *__restrict__ Yv,
-                                                  float *__restrict__ DX, float *__restrict__ DW, float *__restrict__ DB) {
+                                                  float *__restrict__ DX, float *__restrict__ DW, float *__restrict__ DB,
+                                                  const float *__restrict__ OBS, int KO, float *__restrict__ DW1,
+                                                  float *__restrict__ DB1) {
     constexpr int K = 16 * KT, O = 16 * OT;
-    constexpr int ZF = ROWS * O, XF = ROWS * K, BUF = ZF + XF;
+    constexpr int ZF = ROWS * O, XF = ROWS * K, OF = ROWS * WO, BUF = ZF + XF + OF;
+    static_assert(WO == 0 || (!RAG && LAYOUT == 0), "the chained form is the nn.Linear layout with full-width x rows");
     constexpr int WA = LAYOUT == 0 ? O : K, WB = LAYOUT == 0 ? K : O;   // dW is [WA][WB]
     constexpr int NA = WA / 16, NBH = WB / 32;                          // A tiles; B tiles of this wave's half
     constexpr int NKT = KT / 2;                                         // dx column tiles per wave
@@ -141,8 +148,17 @@ __global__ __launch_bounds__(TPB) void bwd_kernel(long R, int KR, const float *_
     for (float &z : zsum) z = 0.0f;
 
     // dx: row tile rg, input-feature tiles kt = hb * NKT + i; wf[i][4 oq + u] = W(k = 16 kt + c, o = 16 oq + 4 g + u)
+    v4f acc1[4];                                          // chained form: this wave's four dW tiles (see the weight-gradient step)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc1[j] = (v4f){ 0.f, 0.f, 0.f, 0.f };
+    float zs1 = 0.0f;
+    constexpr int NOB = WO > 0 ? WO / 16 : 1;            // chained form: this wave's dW1 tiles = x columns 16 wave .. +15 x every obs tile
+    v4f acc2[NOB];
+#pragma unroll
+    for (int j = 0; j < NOB; ++j) acc2[j] = (v4f){ 0.f, 0.f, 0.f, 0.f };
+    float dbsum1 = 0.0f;
     float wf[RAG ? 1 : NKT][RAG ? 1 : 4 * OT];
-    if constexpr (!RAG) if (DX) {
+    if constexpr (!RAG) if (DX || WO > 0) {
 #pragma unroll
         for (int i = 0; i < NKT; ++i) {
             const int k = 16 * (hb * NKT + i) + c;
@@ -179,8 +195,10 @@ __global__ __launch_bounds__(TPB) void bwd_kernel(long R, int KR, const float *_
         } else if (rows < ROWS) {
             for (int p = rows * O + tid; p < ZF; p += TPB) Zs[p] = 0.0f;
         }
-        if (rows < ROWS)
+        if (rows < ROWS) {
             for (int p = rows * K + tid; p < XF; p += TPB) Xs[p] = 0.0f;
+            if constexpr (WO > 0) for (int p = rows * WO + tid; p < OF; p += TPB) Xs[XF + p] = 0.0f;
+        }
     };
     auto issue = [&](float *buf, long chunk) {
         const long r0 = chunk * ROWS;
@@ -189,6 +207,7 @@ __global__ __launch_bounds__(TPB) void bwd_kernel(long R, int KR, const float *_
         issue_tile<O>(b, DY, r0, rows, wave, lane);
         if constexpr (RAG) issue_tile_ragged<K>(b + ZF * (unsigned)sizeof(float), X, r0, rows, KR, wave, lane);
         else issue_tile<K>(b + ZF * (unsigned)sizeof(float), X, r0, rows, wave, lane);
+        if constexpr (WO > 0) issue_tile_ragged<WO>(b + (ZF + XF) * (unsigned)sizeof(float), OBS, r0, rows, KO, wave, lane);
         if (ACT) issue_tile<O>(lds_base + 2 * BUF * (unsigned)sizeof(float), Yv, r0, rows, wave, lane);
         if (DY2) issue_tile<O>(lds_base + (2 * BUF + (ACT ? ZF : 0)) * (unsigned)sizeof(float), DY2, r0, rows, wave, lane);
     };
@@ -208,7 +227,24 @@ __global__ __launch_bounds__(TPB) void bwd_kernel(long R, int KR, const float *_
         const float *As = LAYOUT == 0 ? Zs : Xs, *Bs = LAYOUT == 0 ? Xs : Zs;
         const long r0 = ch * ROWS;
         const int rows = (int)min((long)ROWS, R - r0);
-        // ---- weight gradient: rows 16 rg .. +15 in four k-steps ----
+        // ---- weight gradient ----
+        if constexpr (WO > 0) {
+            // chained form: split by TILES (wave w: z-column tile w / 2, four x-column tiles of half w % 2, all 64 rows) -
+            // 16 accumulator registers instead of 64, complete sums per wave (no cross-wave reduction at the end)
+            static_assert(K == 128 && O == 64, "chained form: the 128 -> 64 encoder layer");
+            const int ua = wave >> 1, ubh = wave & 1;
+#pragma unroll 4
+            for (int kk = 0; kk < ROWS / 4; ++kk) {
+                const int rr = 4 * kk + g;
+                const float a = Zs[chunk_at<O>(rr, c) + ua];                     // z[rr][4 c + ua]: permuted tile ua
+                const float4 b = *reinterpret_cast<const float4 *>(Xs + chunk_at<K>(rr, 16 * ubh + c));
+                acc1[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.x, acc1[0], 0, 0, 0);
+                acc1[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.y, acc1[1], 0, 0, 0);
+                acc1[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.z, acc1[2], 0, 0, 0);
+                acc1[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.w, acc1[3], 0, 0, 0);
+                if (ubh == 0) zs1 += a;
+            }
+        } else
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int r = 16 * rg + 4 * s + g;
@@ -232,7 +268,7 @@ __global__ __launch_bounds__(TPB) void bwd_kernel(long R, int KR, const float *_
             }
         }
         // ---- input gradient, transposed: D[k][row] = sum_o W(k, o) dz[row][o] ----
-        if constexpr (!RAG) if (DX) {
+        if constexpr (!RAG) if (DX || WO > 0) {
             v4f d[NKT];
 #pragma unroll
             for (int i = 0; i < NKT; ++i) d[i] = (v4f){ 0.f, 0.f, 0.f, 0.f };
@@ -248,11 +284,38 @@ __global__ __launch_bounds__(TPB) void bwd_kernel(long R, int KR, const float *_
                     d[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][4 * oq + 3], z.w, d[i], 0, 0, 0);
                 }
             }
-            if (r < rows) {
+            if constexpr (WO == 0) {
+                if (r < rows) {
 #pragma unroll
-                for (int i = 0; i < NKT; ++i)
-                    *reinterpret_cast<float4 *>(DX + (size_t)(r0 + r) * K + 16 * (hb * NKT + i) + 4 * g) =
-                        make_float4(d[i][0], d[i][1], d[i][2], d[i][3]);
+                    for (int i = 0; i < NKT; ++i)
+                        *reinterpret_cast<float4 *>(DX + (size_t)(r0 + r) * K + 16 * (hb * NKT + i) + 4 * g) =
+                            make_float4(d[i][0], d[i][1], d[i][2], d[i][3]);
+                }
+            } else {
+                float *Xw = cur + ZF;
+                __syncthreads();                           // every wave is done reading the x tile (weight gradient above)
+#pragma unroll
+                for (int i = 0; i < NKT; ++i) {           // dz1 = dx * (1 - x^2), in place
+                    float4 *px = reinterpret_cast<float4 *>(Xw + chunk_at<K>(r, 4 * (hb * NKT + i) + g));
+                    const float4 x = *px;
+                    *px = make_float4(d[i][0] * (1.0f - x.x * x.x), d[i][1] * (1.0f - x.y * x.y), d[i][2] * (1.0f - x.z * x.z),
+                                      d[i][3] * (1.0f - x.w * x.w));
+                }
+                __syncthreads();
+                // first layer's weight gradient, one x-column tile per wave over all 64 rows: C[p = x col][q = obs col]
+                const float *Os = cur + ZF + XF;
+#pragma unroll 4
+                for (int kk = 0; kk < ROWS / 4; ++kk) {
+                    const int rr = 4 * kk + g, col = 16 * wave + c;
+                    const float a = Xw[chunk_at<K>(rr, col >> 2) + (col & 3)];
+                    dbsum1 += a;
+#pragma unroll
+                    for (int j = 0; j < NOB; ++j) {
+                        const int oc = 16 * j + c;
+                        const float b = Os[chunk_at<WO>(rr, oc >> 2) + (oc & 3)];
+                        acc2[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc2[j], 0, 0, 0);
+                    }
+                }
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -266,6 +329,35 @@ __global__ __launch_bounds__(TPB) void bwd_kernel(long R, int KR, const float *_
         }
     }
 
+    if constexpr (WO > 0) {
+        // the chained layer's gradients are complete per wave (all rows of all its chunks): straight to HBM
+#pragma unroll
+        for (int j = 0; j < NOB; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = 16 * j + c;
+                if (q < KO) atomicAdd(DW1 + (size_t)(16 * wave + 4 * g + r) * KO + q, acc2[j][r]);
+            }
+        if (DB1) {
+            float v = dbsum1;
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (g == 0) atomicAdd(DB1 + 16 * wave + c, v);
+        }
+        // this layer: C[p = z column 4 (4 g + r) + ua][q = x column 64 ubh + 4 c + j]
+        const int ua = wave >> 1, ubh = wave & 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(DW + (size_t)(4 * (4 * g + r) + ua) * K + 64 * ubh + 4 * c + j, acc1[j][r]);
+        if (DB && ubh == 0) {
+            float v = zs1;
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (g == 0) atomicAdd(DB + 4 * c + ua, v);
+        }
+        return;
+    }
     // ---- reduce the weight-gradient partial sums of the four row groups through LDS; one atomic per element ----
     // lds as [rg][tile][lane] float4; tiles of this half-wave pair: t = i * NBH + j  ->  (ua = i, ub = hb * NBH + j)
     constexpr int NT = NA * NBH;                          // tiles per wave (<= 16)
@@ -330,22 +422,23 @@ __global__ __launch_bounds__(TPB) void bwd_kernel(long R, int KR, const float *_
     }
 }
 
-template <int KT, int OT, int ACT, int LAYOUT, bool RAG = false>
+template <int KT, int OT, int ACT, int LAYOUT, bool RAG = false, int WO = 0>
 static int launch(long R, int KR, const float *x, const float *w, const float *dy, const float *dy2, const float *y, float *dx, float *dw, float *db,
-                  hipStream_t st) {
+                  hipStream_t st, const float *obs = nullptr, int KO = 0, float *dw1 = nullptr, float *db1 = nullptr) {
     constexpr int K = 16 * KT, O = 16 * OT;
-    const size_t lds = ((size_t)2 * ROWS * (K + O) + (ACT ? (size_t)ROWS * O : 0) + (dy2 ? (size_t)ROWS * O : 0)) * sizeof(float);
+    const size_t lds = ((size_t)2 * ROWS * (K + O + WO) + (ACT ? (size_t)ROWS * O : 0) + (dy2 ? (size_t)ROWS * O : 0)) * sizeof(float);
     if (lds > 160 * 1024) return 1;
     static bool attr = false;
     if (!attr) {
-        CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bwd_kernel<KT, OT, ACT, LAYOUT, RAG>),
+        CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bwd_kernel<KT, OT, ACT, LAYOUT, RAG, WO>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
     static const int n_cu = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
     const long chunks = (R + ROWS - 1) / ROWS;
     const int blocks = (int)std::min<long>(chunks, n_cu);
-    hipLaunchKernelGGL((bwd_kernel<KT, OT, ACT, LAYOUT, RAG>), dim3(blocks), dim3(TPB), std::max<size_t>(lds, 33 * 1024), st, R, KR, x, w, dy, dy2, y, dx, dw, db);
+    hipLaunchKernelGGL((bwd_kernel<KT, OT, ACT, LAYOUT, RAG, WO>), dim3(blocks), dim3(TPB), std::max<size_t>(lds, 33 * 1024), st, R, KR, x, w, dy, dy2, y, dx, dw,
+                       db, obs, KO, dw1, db1);
     CM_HIP(hipGetLastError());
     return CM_OK;
 }
@@ -395,6 +488,20 @@ int linear_bwd_stream(long R, int K, int O, const float *x, const float *w, int 
     default: return 1;
     }
 #undef CM_B2
+}
+
+// Encoder backward in one pass (obs [R,d] -> a1 = tanh(.) [R,128] -> e = tanh(.) [R,64]): layer 2 as linear_bwd_stream
+// with dz = (dy + dy2) * (1 - e^2), its input gradient chained in LDS into layer 1's weight / bias gradient.
+// Returns 1 when the shape is not covered (d > 64, unaligned tensors): the caller runs the two layers one by one.
+int encoder_bwd_chain(long R, int d, const float *obs, const float *a1, const float *e, const float *w2, const float *dy, const float *dy2,
+                      float *dw2, float *db2, float *dw1, float *db1, void *stream) {
+    static const bool off = [] { const char *v = getenv("COMMARL_ENC_CHAIN"); return v && v[0] == '0'; }();
+    if (off || d < 1 || d > 64) return 1;
+    if (((uintptr_t)a1 | (uintptr_t)e | (uintptr_t)dy | (uintptr_t)dy2) & 15) return 1;
+    if ((uintptr_t)obs & 3) return 1;
+    const hipStream_t st = (hipStream_t)stream;
+    if (d <= 32) return lin2::launch<8, 4, 1, 0, false, 32>(R, 128, a1, w2, dy, dy2, e, nullptr, dw2, db2, st, obs, d, dw1, db1);
+    return lin2::launch<8, 4, 1, 0, false, 64>(R, 128, a1, w2, dy, dy2, e, nullptr, dw2, db2, st, obs, d, dw1, db1);
 }
 
 }  // namespace cm

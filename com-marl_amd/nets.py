@@ -408,9 +408,20 @@ class _FusedNetFn(torch.autograd.Function):
                                                   L.ptr(dq), L.ptr(dE), L.current_stream()), "cm_attention_backward")
         deq, g["attention_layer.linear_in.weight"], _ = _lin_bwd(e, net.attention_layer.linear_in.weight, 0, dq, None, True, False)
         enc1, enc2 = net.encoder._layers[0].linear, net.encoder._output_layers[0].linear
-        da1, g["encoder._output_layers.0.linear.weight"], g["encoder._output_layers.0.linear.bias"] = _lin_bwd(t["a1"], enc2.weight, 0, dE, e, True, True,
-                                                                                                                dy_add=deq)
-        _, g["encoder._layers.0.linear.weight"], g["encoder._layers.0.linear.bias"] = _lin_bwd(obs2, enc1.weight, 0, da1, t["a1"], False, True)
+        # both encoder layers in one pass (the gradient wrt the hidden layer never leaves the workgroup); wide observations
+        # (d > 64) take the two layers one by one
+        dw2, db2 = torch.zeros_like(enc2.weight), torch.zeros_like(enc2.bias)
+        dw1, db1 = torch.zeros_like(enc1.weight), torch.zeros_like(enc1.bias)
+        with torch.cuda.device(obs2.device):
+            rc = L.lib().cm_encoder_backward(R, obs2.shape[1], L.ptr(obs2), L.ptr(t["a1"]), L.ptr(e), L.ptr(enc2.weight), L.ptr(dE), L.ptr(deq),
+                                             L.ptr(dw2), L.ptr(db2), L.ptr(dw1), L.ptr(db1), L.current_stream())
+        if rc == 1:
+            da1, dw2, db2 = _lin_bwd(t["a1"], enc2.weight, 0, dE, e, True, True, dy_add=deq)
+            _, dw1, db1 = _lin_bwd(obs2, enc1.weight, 0, da1, t["a1"], False, True)
+        else:
+            L.check(rc, "cm_encoder_backward")
+        g["encoder._output_layers.0.linear.weight"], g["encoder._output_layers.0.linear.bias"] = dw2, db2
+        g["encoder._layers.0.linear.weight"], g["encoder._layers.0.linear.bias"] = dw1, db1
         ctx.t = None                                                     # free the saved activations
         return (None, None, None, None) + tuple(g.get(n) for n in ctx.names)
 

@@ -340,6 +340,15 @@ int cm_linear_act_forward(int64_t R, int32_t in_dim, int32_t out_dim, const floa
 int cm_linear_act_backward(int64_t R, int32_t in_dim, int32_t out_dim, const float *x, const float *w, int32_t w_layout,
                            const float *dy, const float *dy2, const float *y, float *dx, float *dw, float *db, void *stream);
 
+/* Backward of the two-layer observation encoder (mlp_encoder_module: obs [R,d] -> a1 = tanh(W1 obs + b1) [R,128] ->
+ * e = tanh(W2 a1 + b2) [R,64]; comm_base_net.py:80-84) in ONE pass over the saved activations: dz2 = (dy + dy2) * (1 - e^2),
+ * dw2 += dz2^T a1, db2 += colsum(dz2); the gradient wrt a1 stays in the workgroup (times tanh' it overwrites the a1 tile) and
+ * gives dw1 += dz1^T obs [128,d], db1 += colsum(dz1).  dy2 / db2 / db1 may be NULL; the caller zeroes dw* / db*.
+ * Returns 1 - nothing done - when the shape is not covered (d > 64, tensors not 16-byte aligned): run the two layers with
+ * cm_linear_act_backward instead. */
+int cm_encoder_backward(int64_t R, int32_t d, const float *obs, const float *a1, const float *e, const float *w2, const float *dy,
+                        const float *dy2, float *dw2, float *db2, float *dw1, float *db1, void *stream);
+
 /* Multi-tensor Adam step with optional gradient-norm clip, two launches for a whole net (csrc/cm_ppo.hip): the vendored
  * torch-1.9 Adam of the reference (com_marl/torch/algos/my_optimizer/_functional.py:72-98, no weight decay / amsgrad) preceded
  * - when norm_ws != NULL - by torch.nn.utils.clip_grad_norm_(params, max_norm) (centralized_ma_ppo.py:253-255), the clipped
