@@ -148,6 +148,10 @@ __global__ __launch_bounds__(TPB) void bwd_kernel(long R, int KR, const float *_
     for (float &z : zsum) z = 0.0f;
 
     // dx: row tile rg, input-feature tiles kt = hb * NKT + i; wf[i][4 oq + u] = W(k = 16 kt + c, o = 16 oq + 4 g + u)
+    constexpr bool TSPLIT = RAG && OT == 8 && WO == 0;
+    v4f accT[TSPLIT ? KT : 1];
+#pragma unroll
+    for (v4f &t : accT) t = (v4f){ 0.f, 0.f, 0.f, 0.f };
     v4f acc1[4];                                          // chained form: this wave's four dW tiles (see the weight-gradient step)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc1[j] = (v4f){ 0.f, 0.f, 0.f, 0.f };
@@ -243,6 +247,21 @@ __global__ __launch_bounds__(TPB) void bwd_kernel(long R, int KR, const float *_
                 acc1[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.z, acc1[2], 0, 0, 0);
                 acc1[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.w, acc1[3], 0, 0, 0);
                 if (ubh == 0) zs1 += a;
+            }
+        } else if constexpr (TSPLIT) {
+            // first layer, 128 outputs: split by tiles as well (wave w: z-column tile w, every x-column tile, all 64 rows):
+            // 4 KT accumulator registers instead of 16 KT - the row-split build of the 128-wide case spilled, and a scratch
+            // reload waits on vmcnt(0), i.e. on the LDS-DMA queue
+#pragma unroll 4
+            for (int kk = 0; kk < ROWS / 4; ++kk) {
+                const int rr = 4 * kk + g;
+                const int zc = col_of<O>(wave, c);
+                const float a = Zs[chunk_at<O>(rr, zc >> 2) + (zc & 3)];
+                float b[KT];
+                load_cols<K, KT>(Xs, rr, c, 0, b);
+#pragma unroll
+                for (int j = 0; j < KT; ++j) accT[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[j], accT[j], 0, 0, 0);
+                zs1 += a;
             }
         } else
 #pragma unroll
@@ -355,6 +374,22 @@ __global__ __launch_bounds__(TPB) void bwd_kernel(long R, int KR, const float *_
             v += __shfl_xor(v, 16);
             v += __shfl_xor(v, 32);
             if (g == 0) atomicAdd(DB + 4 * c + ua, v);
+        }
+        return;
+    }
+    if constexpr (TSPLIT) {
+#pragma unroll
+        for (int j = 0; j < KT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = col_of<K>(j, c);
+                if (q < KR) atomicAdd(DW + (size_t)col_of<O>(wave, 4 * g + r) * KR + q, accT[j][r]);
+            }
+        if (DB) {
+            float v = zs1;
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (g == 0) atomicAdd(DB + col_of<O>(wave, c), v);
         }
         return;
     }
