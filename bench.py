@@ -388,8 +388,8 @@ def main():
                    "parallelism": f"env-sharded x{world} (no data-path collective in the rollout)"},
         "roofline": roofline,
     }
-    if rank == 0 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(c, args.seed, kind=args.policy)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:     # the CPU leg is a single-GPU-run extra (its OpenMP team
+        out["cpu_baseline"] = cpu_baseline(c, args.seed, kind=args.policy)   # would compete with the other ranks' host threads)
     if not args.no_train_loop:
         try:
             from com_marl_amd.train_bench import train_loop_measurement
