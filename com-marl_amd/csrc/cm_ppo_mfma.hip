@@ -42,7 +42,7 @@ __global__ __launch_bounds__(TPB) void agg_bwd_kernel(int S, int N, const float 
                                                      const float *__restrict__ chan, long ch_stride, const float *__restrict__ hw,
                                                      const float *__restrict__ outv, const float *__restrict__ out_minus,
                                                      const float *__restrict__ d_out, float *__restrict__ d_attn,
-                                                     float *__restrict__ d_hw, float *__restrict__ d_bias) {
+                                                     float *__restrict__ d_hw, float *__restrict__ d_bias, int stop) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int NP = np_of(N), NT = NP >> 4, SA = sa_of(NP), NN = N * N;
     float *A = lds;                                       // [NP][SA] normalised A; rows / columns >= N stay zero
@@ -111,6 +111,7 @@ __global__ __launch_bounds__(TPB) void agg_bwd_kernel(int S, int N, const float 
             }
         }
         __syncthreads();
+        if (stop == 1) { __syncthreads(); continue; }                            // (diagnostic: COMMARL_NXN_STOP)
         for (int r = tid >> 4; r < N; r += TPB / 16) {                           // 16 lanes per row
             float *ar = A + (size_t)r * SA;
             float sum = 0.0f;
@@ -121,45 +122,24 @@ __global__ __launch_bounds__(TPB) void agg_bwd_kernel(int S, int N, const float 
         }
         if (d_bias) for (int r = rg; r < N; r += TPB / 64) dbias_acc += DP[(size_t)r * SP + o];
         __syncthreads();
-        // ---- d_hw = A^T . dP: this wave's 16 output features, every row tile ----
-        {
-            v4f acc[MAXNT];
+        if (stop == 2) { __syncthreads(); continue; }
+        // ---- d_hw = A^T . dP: this wave's 16 output features, every row tile (kept in registers for now) ----
+        v4f ahw[MAXNT];
 #pragma unroll
-            for (int t = 0; t < MAXNT; ++t) acc[t] = (v4f){ 0.f, 0.f, 0.f, 0.f };
-            for (int kk = 0; kk < NP / 4; ++kk) {                                 // k = source row i = 4 kk + g
-                const float b = DP[(size_t)(4 * kk + g) * SP + 16 * wave + c];
-                const float *ar = A + (size_t)(4 * kk + g) * SA + c;
-#pragma unroll
-                for (int t = 0; t < MAXNT; ++t)
-                    if (t < NT) acc[t] = mfma4(ar[16 * t], b, acc[t]);
-            }
+        for (int t = 0; t < MAXNT; ++t) ahw[t] = (v4f){ 0.f, 0.f, 0.f, 0.f };
+        for (int kk = 0; kk < NP / 4; ++kk) {                                     // k = source row i = 4 kk + g
+            const float b = DP[(size_t)(4 * kk + g) * SP + 16 * wave + c];
+            const float *ar = A + (size_t)(4 * kk + g) * SA + c;
 #pragma unroll
             for (int t = 0; t < MAXNT; ++t)
-                if (t < NT) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = 16 * t + 4 * g + r;
-                        if (row < N) d_hw[row0 + (size_t)row * E + 16 * wave + c] = acc[t][r];
-                    }
-                }
+                if (t < NT) ahw[t] = mfma4(ar[16 * t], b, ahw[t]);
         }
-        // ---- dA = dP . hw^T, one row tile per wave at a time; through the renormalisation in registers:
-        //      dM_ij = mask_ij (dA_ij - sum_k dA_ik A_ik) / den_i ----
+        __syncthreads();                                                          // every wave is done with the whole of A
+        if (stop == 3) { __syncthreads(); continue; }
+        // ---- dA = dP . hw^T, one row tile per wave at a time; through the renormalisation in registers,
+        //      dM_ij = mask_ij (dA_ij - sum_k dA_ik A_ik) / den_i, written over A IN PLACE without the mask (each position by
+        //      the lane that read it) so that it can leave in whole rows below ----
         for (int it = wave; it < NT; it += TPB / 64) {
-            // the epilogue's mask values: requested before the products, consumed after them
-            float mk[MAXNT][4];
-#pragma unroll
-            for (int t = 0; t < MAXNT; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = 16 * it + 4 * g + r, j = 16 * t + c;
-                    mk[t][r] = 1.0f;
-                    if (t < NT && i < N && j < N) {
-                        const size_t k = (size_t)i * N + j;
-                        if (adj) mk[t][r] = adj[base + k];
-                        if (chan) mk[t][r] *= chan[(size_t)s * ch_stride + k];
-                    }
-                }
             v4f acc[MAXNT];
 #pragma unroll
             for (int t = 0; t < MAXNT; ++t) acc[t] = (v4f){ 0.f, 0.f, 0.f, 0.f };
@@ -177,20 +157,57 @@ __global__ __launch_bounds__(TPB) void agg_bwd_kernel(int S, int N, const float 
 #pragma unroll
                     for (int r = 0; r < 4; ++r) tt[r] = fmaf(acc[t][r], A[(size_t)(16 * it + 4 * g + r) * SA + 16 * t + c], tt[r]);
                 }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) tt[r] = row_sum16(tt[r]);
             float rden[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) rden[r] = 1.0f / den[min(16 * it + 4 * g + r, NP - 1)];
+            for (int r = 0; r < 4; ++r) { tt[r] = row_sum16(tt[r]); rden[r] = 1.0f / den[min(16 * it + 4 * g + r, N - 1)]; }
 #pragma unroll
             for (int t = 0; t < MAXNT; ++t)
                 if (t < NT) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int i = 16 * it + 4 * g + r, j = 16 * t + c;
-                        if (i < N && j < N) d_attn[base + (size_t)i * N + j] = mk[t][r] * (acc[t][r] - tt[r]) * rden[r];
-                    }
+                    for (int r = 0; r < 4; ++r)
+                        if (16 * it + 4 * g + r < N && 16 * t + c < N)                     // the zero padding stays zero
+                            A[(size_t)(16 * it + 4 * g + r) * SA + 16 * t + c] = (acc[t][r] - tt[r]) * rden[r];
                 }
+        }
+        __syncthreads();                                                          // HW and dP are dead, A holds dM (unmasked)
+#pragma unroll
+        for (int t = 0; t < MAXNT; ++t)
+            if (t < NT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) HW[(size_t)(16 * t + 4 * g + r) * SP + 16 * wave + c] = ahw[t][r];
+            }
+        __syncthreads();
+        // ---- both results leave in whole rows: 16-byte stores (the accumulator layout would give 64-byte pieces of rows) ----
+        {
+            float4 *o4 = reinterpret_cast<float4 *>(d_hw + row0);
+            for (int k = tid; k < N * (E / 4); k += TPB) o4[k] = *reinterpret_cast<const float4 *>(HW + (size_t)(k >> 4) * SP + 4 * (k & 15));
+            if ((NN & 3) == 0) {
+                const float4 *j4 = adj ? reinterpret_cast<const float4 *>(adj + base) : nullptr;
+                const float4 *c4 = chan ? reinterpret_cast<const float4 *>(chan + (size_t)s * ch_stride) : nullptr;
+                const bool c_al = !chan || ((((size_t)s * ch_stride) & 3) == 0);
+                float4 *m4 = reinterpret_cast<float4 *>(d_attn + base);
+                for (int k4 = tid; k4 < NN / 4; k4 += TPB) {
+                    float4 mk = j4 ? j4[k4] : make_float4(1.f, 1.f, 1.f, 1.f);
+                    if (chan) {
+                        if (c_al) { const float4 u = c4[k4]; mk.x *= u.x; mk.y *= u.y; mk.z *= u.z; mk.w *= u.w; }
+                        else { const float *cp = chan + (size_t)s * ch_stride + 4 * k4; mk.x *= cp[0]; mk.y *= cp[1]; mk.z *= cp[2]; mk.w *= cp[3]; }
+                    }
+                    float v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int k = 4 * k4 + u, i = (int)(((float)k + 0.5f) * rcpN), j = k - i * N;
+                        v[u] = A[(size_t)i * SA + j];
+                    }
+                    m4[k4] = make_float4(mk.x * v[0], mk.y * v[1], mk.z * v[2], mk.w * v[3]);
+                }
+            } else {
+                for (int k = tid; k < NN; k += TPB) {
+                    const int i = (int)(((float)k + 0.5f) * rcpN), j = k - i * N;
+                    float mk = adj ? adj[base + k] : 1.0f;
+                    if (chan) mk *= chan[(size_t)s * ch_stride + k];
+                    d_attn[base + k] = mk * A[(size_t)i * SA + j];
+                }
+            }
         }
         __syncthreads();
     }
@@ -273,19 +290,6 @@ __global__ __launch_bounds__(TPB) void attn_bwd_kernel(int S, int N, const float
         v4f aq[MAXNT], ae[MAXNT];
 #pragma unroll
         for (int t = 0; t < MAXNT; ++t) { aq[t] = (v4f){ 0.f, 0.f, 0.f, 0.f }; ae[t] = aq[t]; }
-        float adv[MAXNT][4];                                                       // the addends of d_e: requested before the products
-#pragma unroll
-        for (int t = 0; t < MAXNT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 16 * t + 4 * g + r;
-                adv[t][r] = 0.0f;
-                if (t < NT && row < N) {
-                    const size_t at = row0 + (size_t)row * E + 16 * wave + c;
-                    if (add0) adv[t][r] = add0[at];
-                    if (add1) adv[t][r] += add1[at];
-                }
-            }
         for (int kk = 0; kk < NP / 4; ++kk) {
             const float be = K[(size_t)(4 * kk + g) * SR + 16 * wave + c];        // e[j = 4 kk + g]
             const float bq = Q[(size_t)(4 * kk + g) * SR + 16 * wave + c];        // q[i = 4 kk + g]
@@ -298,19 +302,30 @@ __global__ __launch_bounds__(TPB) void attn_bwd_kernel(int S, int N, const float
                     ae[t] = mfma4(dst[16 * t], bq, ae[t]);
                 }
         }
+        __syncthreads();                                                          // Q and K are dead: the results take their place
 #pragma unroll
         for (int t = 0; t < MAXNT; ++t)
             if (t < NT) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * t + 4 * g + r;
-                    if (row < N) {
-                        const size_t at = row0 + (size_t)row * E + 16 * wave + c;
-                        d_q[at] = aq[t][r];
-                        d_e[at] = ae[t][r] + adv[t][r];
-                    }
+                    Q[(size_t)(16 * t + 4 * g + r) * SR + 16 * wave + c] = aq[t][r];
+                    K[(size_t)(16 * t + 4 * g + r) * SR + 16 * wave + c] = ae[t][r];
                 }
             }
+        __syncthreads();
+        {   // whole rows out, 16 bytes per lane; the addends of d_e come in the same way
+            float4 *q4o = reinterpret_cast<float4 *>(d_q + row0), *e4o = reinterpret_cast<float4 *>(d_e + row0);
+            const float4 *a04 = add0 ? reinterpret_cast<const float4 *>(add0 + row0) : nullptr;
+            const float4 *a14 = add1 ? reinterpret_cast<const float4 *>(add1 + row0) : nullptr;
+            for (int k = tid; k < N * (E / 4); k += TPB) {
+                const int r = k >> 4, x = k & 15;
+                q4o[k] = *reinterpret_cast<const float4 *>(Q + (size_t)r * SR + 4 * x);
+                float4 v = *reinterpret_cast<const float4 *>(K + (size_t)r * SR + 4 * x);
+                if (a04) { const float4 u = a04[k]; v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+                if (a14) { const float4 u = a14[k]; v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+                e4o[k] = v;
+            }
+        }
         __syncthreads();
     }
 }
@@ -329,8 +344,9 @@ static int launch_agg(int S, int N, const float *attn, const float *adj, const f
     const size_t lds = agg_lds(N);
     static bool once = false;
     if (!once) { CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_bwd_kernel<MAXNT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
+    static const int stop = [] { const char *e = getenv("COMMARL_NXN_STOP"); return e ? atoi(e) : 0; }();
     hipLaunchKernelGGL(agg_bwd_kernel<MAXNT>, dim3(blocks_for(S, lds)), dim3(TPB), lds, st, S, N, attn, adj, chan, ch_stride, hw, out, out_minus,
-                       d_out, d_attn, d_hw, d_bias);
+                       d_out, d_attn, d_hw, d_bias, stop);
     CM_HIP(hipGetLastError());
     return CM_OK;
 }
@@ -357,7 +373,7 @@ static bool mfma_bwd_on() {
 int agg_bwd_mfma(int S, int N, const float *attn, const float *adj, const float *chan, long ch_stride, const float *hw, const float *out,
                  const float *out_minus, const float *d_out, float *d_attn, float *d_hw, float *d_bias, void *stream) {
     if (!mfma_bwd_on() || N < 8 || N > 128) return 1;
-    if (((uintptr_t)hw | (uintptr_t)out | (uintptr_t)out_minus | (uintptr_t)d_out) & 15) return 1;
+    if (((uintptr_t)hw | (uintptr_t)out | (uintptr_t)out_minus | (uintptr_t)d_out | (uintptr_t)d_hw | (uintptr_t)adj | (uintptr_t)d_attn) & 15) return 1;
     if (pm::agg_lds(N) > 160 * 1024) return 1;
     const hipStream_t st = (hipStream_t)stream;
     const int NT = pm::np_of(N) / 16;
@@ -369,7 +385,7 @@ int agg_bwd_mfma(int S, int N, const float *attn, const float *adj, const float 
 int attn_bwd_mfma(int S, int N, const float *q, const float *e, const float *m, const float *d_m, const float *add0, const float *add1,
                   float *d_q, float *d_e, void *stream) {
     if (!mfma_bwd_on() || N < 8 || N > 128) return 1;
-    if (((uintptr_t)q | (uintptr_t)e) & 15) return 1;
+    if (((uintptr_t)q | (uintptr_t)e | (uintptr_t)add0 | (uintptr_t)add1 | (uintptr_t)d_q | (uintptr_t)d_e) & 15) return 1;
     if (pm::attn_lds(N) > 160 * 1024) return 1;
     const hipStream_t st = (hipStream_t)stream;
     const int NT = pm::np_of(N) / 16;
