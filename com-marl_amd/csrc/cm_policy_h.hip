@@ -20,6 +20,15 @@ __global__ __launch_bounds__(64 * NW) void fwd_h_kernel(FwdArgs a, TrunkH tw, Po
     fwd_body_h<HEAD, KH, MAXMK, NW>(a, tw, ph, chd, lds_h, blockIdx.x, nullptr);
 }
 
+// Teams of 4 at TRAINING batch sizes (tens of thousands of workgroups): the same body with late weight fetches, held to
+// three waves per SIMD (<= 168 VGPRs) so that three workgroups share a CU instead of two - the rollout's 512 workgroups
+// cannot use a third slot, a 34 k-workgroup grid can.
+template <int HEAD, int KH>
+__global__ __launch_bounds__(256, 3) void fwd_h_occ3_kernel(FwdArgs a, TrunkH tw, PolHeadH ph, CritHeadH chd) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_h[];
+    fwd_body_h<HEAD, KH, -1, 4, true, true>(a, tw, ph, chd, lds_h, blockIdx.x, nullptr);
+}
+
 template <int HEAD, int KH, int MAXMK, int NW = 4>
 static int launch_h(FwdArgs a, const TrunkH &tw, const PolHeadH &ph, const CritHeadH &chd, void *stream) {
     a.EPB = mf::pick_epb(a.N);
@@ -33,6 +42,19 @@ static int launch_h(FwdArgs a, const TrunkH &tw, const PolHeadH &ph, const CritH
         attr_set = true;
     }
     const int blocks = (a.S + a.EPB - 1) / a.EPB;
+    if constexpr (MAXMK < 0 && NW == 4) {
+        static const int occ_min = [] { const char *e = getenv("COMMARL_FWD_OCC3_MIN"); return e ? atoi(e) : 4096; }();   // workgroups; 0 = never
+        if (occ_min > 0 && blocks >= occ_min) {
+            static bool attr3 = false;
+            if (!attr3) {
+                CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fwd_h_occ3_kernel<HEAD, KH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr3 = true;
+            }
+            hipLaunchKernelGGL((fwd_h_occ3_kernel<HEAD, KH>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, a, tw, ph, chd);
+            CM_HIP(hipGetLastError());
+            return CM_OK;
+        }
+    }
     hipLaunchKernelGGL((fwd_h_kernel<HEAD, KH, MAXMK, NW>), dim3(blocks), dim3(64 * NW), lds, (hipStream_t)stream, a, tw, ph, chd);
     CM_HIP(hipGetLastError());
     return CM_OK;

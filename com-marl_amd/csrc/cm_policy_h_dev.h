@@ -407,11 +407,16 @@ __host__ __device__ inline LdsMap lds_map(int rows_cap, int epb, int N, int mode
 // the VALU, > 0 large teams on MFMA tiles); NW = waves per workgroup
 // SAVES = false compiles the training-forward stores out (the fused rollout kernels: their per-step copy of the argument
 // block then has no dynamically indexed member and stays in registers instead of scratch)
-template <int HEAD, int KH, int MAXMK, int NW = 4, bool SAVES = true>
+// LATE (teams of 4 only) = every layer's weight fragments are fetched right before the layer instead of one or two layers
+// ahead: fewer live registers, for the high-occupancy build that training-size grids use (cm_policy_h.hip)
+#define CM_EARLY(x) do { if constexpr (!LATE) { x; } } while (0)
+#define CM_JIT(x) do { if constexpr (LATE) { x; } } while (0)
+template <int HEAD, int KH, int MAXMK, int NW = 4, bool SAVES = true, bool LATE = false>
 __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, const PolHeadH &ph, const CritHeadH &chd,
                                            unsigned char *lds, int blk, int32_t *act_lds) {
     constexpr int TPBW = 64 * NW, NG = 4 * NW;
     static_assert(NW == 4 || (NW == 8 && MAXMK > 0), "8-wave workgroups are built for the large-team path only");
+    static_assert(!LATE || MAXMK < 0, "the late-fetch build exists for the teams-of-4 path");
     constexpr bool quad_path = MAXMK < 0;
     constexpr bool big = MAXMK > 0;
     const int tid = thread_x(), wave = tid >> 6, lane = tid & 63;
@@ -441,24 +446,25 @@ __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, c
     LayerH<KH, EH, NW> l_enc1;
     l_enc1.load(tw.enc1_p, tw.enc_b1, wave, lane);
     LayerH<EH, EMB, NW> l_enc2;
-    l_enc2.load(tw.enc2_p, tw.enc_b2, wave, lane);
+    CM_EARLY(l_enc2.load(tw.enc2_p, tw.enc_b2, wave, lane));
     const uint32_t draw_step = a.policy_step + (a.step_base ? *a.step_base : 0u);
     lds_barrier();
     if (a.stop == 1) return;
     l_enc1.template run<true, OUT_PLANES>(Xp, Ap, nullptr, 0, RT, wave, lane);
     LayerH<EMB, EMB, NW> l_sq;                               // 64 x 64 square layers: attention, then (non-quad) the hops
-    l_sq.load(tw.attn_p, nullptr, wave, lane);
+    CM_EARLY(l_sq.load(tw.attn_p, nullptr, wave, lane));
     LayerH<EMB, EMB, NW> l_g;                                // quad path: GCN weights, one hop ahead
-    if (quad_path && L > 0) l_g.load(tw.gcn_p, nullptr, wave, lane);
+    if (quad_path && L > 0) CM_EARLY(l_g.load(tw.gcn_p, nullptr, wave, lane));
     lds_barrier();
     if (a.stop == 2) return;
+    CM_JIT(l_enc2.load(tw.enc2_p, tw.enc_b2, wave, lane));
     if (quad_path || big) l_enc2.template run<true, OUT_PLANES>(Ap, Ep, nullptr, 0, RT, wave, lane);
     else l_enc2.template run<true, OUT_PLANES | OUT_F32>(Ap, Ep, EF, SF, RT, wave, lane);
     const size_t grow0 = (size_t)s0 * N;                     // first global agent row of this workgroup
     if (sv_on) dump_planes<128, TPBW>(Ap, a.sv_a1, grow0, rows, tid);                        // encoder hidden layer
     LayerH<EMB, HEAD == 0 ? H1 : DH, NW> l_x1;               // first head layer (policy 64 -> 128, critic 64 -> 64)
     LayerH<H1, H2, NW> l_h2;
-    if (quad_path) l_x1.load(HEAD == 0 ? ph.h1_p : chd.d1_p, HEAD == 0 ? ph.b1 : chd.b1, wave, lane);
+    if (quad_path) CM_EARLY(l_x1.load(HEAD == 0 ? ph.h1_p : chd.d1_p, HEAD == 0 ? ph.b1 : chd.b1, wave, lane));
     lds_barrier();
     if (a.stop == 3) return;
 
@@ -466,14 +472,16 @@ __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, c
         // ---- teams of 4: attention and aggregation in registers (see cm_policy_mfma_dev.h for the layout argument) ----
         const int c = lane & 15, g = lane >> 4, q = lane & 3;
         const bool diag = (c >> 2) == g;
+        CM_JIT(l_sq.load(tw.attn_p, nullptr, wave, lane));
         l_sq.template run<false, OUT_PLANES>(Ep, Tp, nullptr, 0, RT, wave, lane);           // Q = E.Wa^T  -> planes in T
         float *HW0 = reinterpret_cast<float *>(lds + lm.r1);                               // H.Wg_l f32: hop parity picks the
         float *HW1 = HW0 + (size_t)rows_cap * SF;                                           // half of R1 (enc1 output is dead)
         if (L > 0) {
+            CM_JIT(l_g.load(tw.gcn_p, nullptr, wave, lane));
             l_g.template run<false, OUT_F32>(Ep, Ep, HW0, SF, RT, wave, lane);             // H.Wg_0 (hop 0 reads E)
-            if (L > 1) l_g.load(tw.gcn_p + LayerH<EMB, EMB, NW>::PACK_U4, nullptr, wave, lane);
+            if (L > 1) CM_EARLY(l_g.load(tw.gcn_p + LayerH<EMB, EMB, NW>::PACK_U4, nullptr, wave, lane));
         }
-        if (HEAD == 0) l_h2.load(ph.h2_p, ph.b2, wave, lane);
+        if (HEAD == 0) CM_EARLY(l_h2.load(ph.h2_p, ph.b2, wave, lane));
         if (sv_on) dump_planes<64, TPBW>(Ep, a.sv_e, grow0, rows, tid);
         lds_barrier();
         if (a.stop == 4) return;
@@ -556,8 +564,9 @@ __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, c
             if (a.stop == 61 + l) return;
             if (sv_on && l < 4) dump_planes<64, TPBW>(Hp, a.sv_h[l], grow0, rows, tid);      // hop output (last: + residual)
             if (!last) {
+                CM_JIT(l_g.load(tw.gcn_p + (size_t)(l + 1) * LayerH<EMB, EMB, NW>::PACK_U4, nullptr, wave, lane));
                 l_g.template run<false, OUT_F32>(Hp, Hp, (l & 1) ? HW0 : HW1, SF, RT, wave, lane);     // H.Wg_{l+1}
-                if (l + 2 < L) l_g.load(tw.gcn_p + (size_t)(l + 2) * LayerH<EMB, EMB, NW>::PACK_U4, nullptr, wave, lane);
+                if (l + 2 < L) CM_EARLY(l_g.load(tw.gcn_p + (size_t)(l + 2) * LayerH<EMB, EMB, NW>::PACK_U4, nullptr, wave, lane));
                 lds_barrier();
                 if (sv_on && l + 1 < 4) dump_f32<64, TPBW>((l & 1) ? HW0 : HW1, SF, a.sv_hw[l + 1], grow0, rows, tid);
             }
@@ -885,15 +894,18 @@ __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, c
     if (HEAD == 0) {
         if (big) l_h2.load(ph.h2_p, ph.b2, wave, lane);
         LayerH<H2, H3, NW> l_h3;
-        l_h3.load(ph.h3_p, ph.b3, wave, lane);
+        CM_EARLY(l_h3.load(ph.h3_p, ph.b3, wave, lane));
+        CM_JIT(l_x1.load(ph.h1_p, ph.b1, wave, lane));
         l_x1.template run<true, OUT_PLANES>(Hp, Ap, nullptr, 0, RT, wave, lane);             // 64 -> 128 into R1
         lds_barrier();
+        CM_JIT(l_h2.load(ph.h2_p, ph.b2, wave, lane));
         l_h2.template run<true, OUT_PLANES>(Ap, Tp, nullptr, 0, RT, wave, lane);             // 128 -> 64 into T
         if (sv_on) dump_planes<128, TPBW>(Ap, a.sv_x1, grow0, rows, tid);
         const int A = ph.n_act;
         LayerH<H3, 16, NW> l_h4;                             // 32 -> n_act (<= 8) logits, zero-padded to one feature tile
-        l_h4.load(ph.h4_p, ph.b4, wave, lane, A);
+        CM_EARLY(l_h4.load(ph.h4_p, ph.b4, wave, lane, A));
         lds_barrier();
+        CM_JIT(l_h3.load(ph.h3_p, ph.b3, wave, lane));
         l_h3.template run<true, OUT_PLANES>(Tp, Gp, nullptr, 0, RT, wave, lane);             // 64 -> 32 into EP
         if (sv_on) dump_planes<64, TPBW>(Tp, a.sv_x2, grow0, rows, tid);
         lds_barrier();
@@ -907,6 +919,7 @@ __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, c
                 const u32x4 xr = philox4x32_10((uint32_t)(a.env_id_offset + s0 + e), draw_step, SITE_ACTION, (uint32_t)i, a.key0, a.key1);
                 rs[r] = unit_f32(xr.x);
             }
+        CM_JIT(l_h4.load(ph.h4_p, ph.b4, wave, lane, A));
         l_h4.template run<false, OUT_F32>(Gp, Gp, LG, SLG, RT, wave, lane);                  // logits f32 into T
         if (sv_on) dump_planes<32, TPBW>(Gp, a.sv_x3, grow0, rows, tid);
         lds_barrier();
@@ -957,6 +970,7 @@ __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, c
         store_attention();
     } else {
         float *XF = reinterpret_cast<float *>(lds + lm.r1);                                  // critic: tanh(x1) f32 [rows][SF] in R1
+        CM_JIT(l_x1.load(chd.d1_p, chd.b1, wave, lane));
         l_x1.template run<true, OUT_F32>(Hp, Hp, XF, SF, RT, wave, lane);
         lds_barrier();
         if (sv_on) dump_f32<64, TPBW>(XF, SF, a.sv_x1, grow0, rows, tid);
