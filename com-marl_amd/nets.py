@@ -1056,11 +1056,14 @@ class DecCategoricalMLPPolicy(_RowMLPPolicy, MLPModule):
         return ([(l.linear, True) for l in e._layers] + [(e._output_layers[0].linear, True)]
                 + [(l.linear, True) for l in self._layers] + [(self._output_layers[0].linear, False)])
 
-    def _probs(self, obs_n, avail_actions_n, dist_adj=None, channels=None):
+    def _logits(self, obs_n, dist_adj=None, channels=None):
+        """Raw per-agent logits [..., N, A] (what CentralizedMAPPO's one-launch surrogate loss consumes)."""
         self._need_gpu(obs_n)
         obs = obs_n.reshape(obs_n.shape[:-1] + (self._n_agents, -1))              # :110
-        logits = MLPModule.forward(self, self.encoder(obs))
-        return self._masked(logits, avail_actions_n), None
+        return MLPModule.forward(self, self.encoder(obs))
+
+    def _probs(self, obs_n, avail_actions_n, dist_adj=None, channels=None):
+        return self._masked(self._logits(obs_n), avail_actions_n), None
 
 
 class CentralizedCategoricalMLPPolicy(_RowMLPPolicy, MLPModule):
@@ -1082,11 +1085,14 @@ class CentralizedCategoricalMLPPolicy(_RowMLPPolicy, MLPModule):
     def _chain(self):
         return [(l.linear, True) for l in self._layers] + [(self._output_layers[0].linear, False)]
 
-    def _probs(self, obs_n, avail_actions_n, dist_adj=None, channels=None):
+    def _logits(self, obs_n, dist_adj=None, channels=None):
+        """Raw logits [..., N, A] (what CentralizedMAPPO's one-launch surrogate loss consumes)."""
         self._need_gpu(obs_n)
         logits = MLPModule.forward(self, obs_n)
-        logits = logits.reshape(logits.shape[:-1] + (self._n_agents, -1))         # :83
-        return self._masked(logits, avail_actions_n), None
+        return logits.reshape(logits.shape[:-1] + (self._n_agents, -1))           # :83
+
+    def _probs(self, obs_n, avail_actions_n, dist_adj=None, channels=None):
+        return self._masked(self._logits(obs_n), avail_actions_n), None
 
 
 class GaussianMLPBaseline(_WeightPack, nn.Module):
