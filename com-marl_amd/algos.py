@@ -16,6 +16,7 @@ all-reduce of the flat (policy ‖ critic ‖ counts) gradient bucket per optimi
 """
 import collections
 import copy
+import os
 import time
 
 import numpy as np
@@ -55,7 +56,6 @@ class _SurrogateFn(torch.autograd.Function):
 
 
 def _fused_loss_ok(policy, obs, avail_actions, actions, valids):
-    import os
     return (obs.is_cuda and avail_actions is None and hasattr(policy, "_logits") and policy._action_dim <= 8
             and actions.dtype == torch.int32 and valids.dtype == torch.int32 and os.environ.get("COMMARL_FUSED_LOSS", "1") != "0")
 
@@ -386,7 +386,6 @@ class CentralizedMAPPO:
                                 sl(channels, ids), advantages[ids], old_ll[ids], returns[ids]))
         # The critic has its own trunk (a-17): its forward / backward (/ optimiser step) share nothing with the policy's
         # but the minibatch, so they run on a second HIP stream and fill the gaps of the policy's launch chain.
-        import os
         main = torch.cuda.current_stream(obs.device)
         side = main
         if obs.is_cuda and os.environ.get("COMMARL_CRITIC_STREAM", "1") != "0":

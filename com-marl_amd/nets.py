@@ -290,12 +290,17 @@ def _lin_bwd(x2, w, layout, dy2, y2, want_dx, has_bias, dy_add=None):
     return dx, dw, db
 
 
-def _fused_train_ok(net, obs):
+def _fused_shape_ok(net, obs):
+    """Shapes with a saved-forward instantiation (cm_*_forward_saved) and a backward chain."""
     # teams above 80 agents exceed the f16-split forward's LDS budget (its activation planes + the N x N score matrix):
     # they keep the per-layer path
-    return (obs.is_cuda and torch.is_grad_enabled() and 1 <= net._n_agents <= 80 and 1 <= len(net.gcn_layers) <= 4
+    return (obs.is_cuda and 1 <= net._n_agents <= 80 and 1 <= len(net.gcn_layers) <= 4
             and net._dec_obs_dim <= 96 and len(net.encoder._layers) == 1
             and os.environ.get("COMMARL_FUSED_TRAIN", "1") != "0" and os.environ.get("COMMARL_POLICY_KERNEL", "")[:1] not in ("f", "v"))
+
+
+def _fused_train_ok(net, obs):
+    return torch.is_grad_enabled() and _fused_shape_ok(net, obs)
 
 
 class _FusedNetFn(torch.autograd.Function):
@@ -637,11 +642,8 @@ class CommCategoricalMLPPolicy(CommBaseNet):
         fused_shape = len(self.categorical_output_layer._layers) == 3
         if _fused_train_ok(self, obs) and fused_shape:
             return _FusedNetFn.apply(self, obs, adj, ch, *self.parameters())          # one forward launch + hand-written backward
-        if not torch.is_grad_enabled() and fused_shape:
-            with torch.enable_grad():
-                ok = _fused_train_ok(self, obs)
-            if ok:
-                return _fused_logits_nograd(self, obs, adj, ch)
+        if not torch.is_grad_enabled() and fused_shape and _fused_shape_ok(self, obs):
+            return _fused_logits_nograd(self, obs, adj, ch)
         E, H, M = self.trunk(obs, adj, ch)
         x = E + H if self.residual else H
         return self.categorical_output_layer(x), M
@@ -653,9 +655,7 @@ class CommCategoricalMLPPolicy(CommBaseNet):
         else the probabilities from act_device and no logits."""
         lead, S, obs, adj, ch = self._flatten(obs_n, dist_adj, channels)
         N = self._n_agents
-        with torch.enable_grad():
-            ok = _fused_train_ok(self, obs) and len(self.categorical_output_layer._layers) == 3
-        if ok:
+        if _fused_shape_ok(self, obs) and len(self.categorical_output_layer._layers) == 3:
             logits, probs = _fused_logits_nograd(self, obs, adj, ch, want_probs=True)
             return logits.reshape(*lead, N, -1), probs.reshape(*lead, N, -1)
         _, probs, _ = self.act_device(obs.reshape(S, -1), None, adj, ch, want_actions=False, want_attn=False, policy_step=0)
