@@ -1,6 +1,6 @@
 #!/bin/bash
-# kernel-trace of the driver's short run (--steps 20 --warmup 5): timeline of the LAST 20 steps' rollout kernels -
-# gaps before / between / after them (where the fixed cost of a short timed region sits)
+# kernel trace of the driver's short run (--steps 20 --warmup 5): groups of back-to-back fused-step launches (a group = one
+# graph replay), their span, summed kernel time and the gaps between launches - where a short timed region's time goes
 set -e
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
@@ -9,21 +9,24 @@ rocprofv3 --kernel-trace --output-format csv -d /tmp/ktrace -o t -- python3 $ROO
 python3 - <<'PY'
 import csv, glob
 f = glob.glob("/tmp/ktrace/**/*kernel_trace.csv", recursive=True)[0]
-rows = list(csv.DictReader(open(f)))
+rows = [r for r in csv.DictReader(open(f))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# the rollout kernels of the timed region are the last 80 (20 steps x 2 shards x 2 kernels) BEFORE the per-kernel timing section
-idx = [i for i, r in enumerate(rows) if "fwd_mfma" in r["Kernel_Name"] or "env_kernel" in r["Kernel_Name"]]
-# warmup 5 steps -> 20 kernels (+ scratch step 4), then timed 80; find them: after reset kernels
-roll = idx[:]
-print("rollout-type kernels total", len(roll))
-# take kernels number 24+.. heuristically: print a timeline of everything between the first and the 110th rollout kernel
-lo, hi = roll[0], roll[min(len(roll) - 1, 130)]
-t0 = int(rows[lo]["Start_Timestamp"])
-prev_end = t0
-for r in rows[lo:hi + 1]:
-    s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-    name = r["Kernel_Name"]
-    tag = "P" if "fwd_mfma" in name else ("E" if "env_kernel" in name else name[:40])
-    print(f"{(s - t0) / 1e3:9.1f} {(e - t0) / 1e3:9.1f}  dur {(e - s) / 1e3:6.1f}  gap_from_prev_end {(s - prev_end) / 1e3:7.1f}  q{r.get('Queue_Id','?')} {tag}")
-    prev_end = max(prev_end, e)
+groups, cur = [], []
+for r in rows:
+    if "rollout_step_kernel" not in r["Kernel_Name"] and "chunk_tail" not in r["Kernel_Name"]:
+        if cur: groups.append(cur); cur = []
+        continue
+    s = int(r["Start_Timestamp"])
+    if cur and s - int(cur[-1]["End_Timestamp"]) > 20000:
+        groups.append(cur); cur = []
+    cur.append(r)
+if cur: groups.append(cur)
+for g in groups[:8]:
+    ks = [r for r in g if "rollout_step" in r["Kernel_Name"]]
+    if len(ks) < 5: continue
+    span = (int(g[-1]["End_Timestamp"]) - int(g[0]["Start_Timestamp"])) / 1e3
+    durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in ks]
+    gaps = [(int(b["Start_Timestamp"]) - int(a["End_Timestamp"])) / 1e3 for a, b in zip(g[:-1], g[1:])]
+    print(f"group of {len(ks):3d} steps: span {span:7.1f} us, kernel time {sum(durs):7.1f} us (mean {sum(durs)/len(durs):5.2f}, min {min(durs):5.2f}, max {max(durs):5.2f}), "
+          f"gaps mean {sum(gaps)/max(len(gaps),1):4.2f} max {max(gaps) if gaps else 0:4.2f} us")
 PY
