@@ -504,7 +504,9 @@ __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, c
         const size_t env_g = (size_t)s0 + min(env_l, envs - 1);
         if (a.attn && ch == 0 && live) {
             float *dst = a.attn + env_g * 16 + q;
-            dst[0] = m[0]; dst[4] = m[1]; dst[8] = m[2]; dst[12] = m[3];
+            // (trajectory outputs nobody reads during the rollout: streamed past the caches)
+            __builtin_nontemporal_store(m[0], dst); __builtin_nontemporal_store(m[1], dst + 4);
+            __builtin_nontemporal_store(m[2], dst + 8); __builtin_nontemporal_store(m[3], dst + 12);
         }
         if (a.stop == 5) return;
         for (int l = 0; l < L; ++l) {
@@ -947,7 +949,7 @@ __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, c
             for (int cc = 0; cc < MAX_ACT; ++cc) if (cc < A) p[cc] = p[cc] * rmsum;
             if (a.probs) {
 #pragma unroll
-                for (int cc = 0; cc < MAX_ACT; ++cc) if (cc < A) a.probs[grow * A + cc] = p[cc];
+                for (int cc = 0; cc < MAX_ACT; ++cc) if (cc < A) __builtin_nontemporal_store(p[cc], a.probs + grow * A + cc);
             }
             if (a.actions || act_lds) {
                 int act = 0;
