@@ -6,7 +6,7 @@ if len(sys.argv) > 1:
     from com_marl_amd import envs as E, nets
     import bench
     c = dict(bench.CONFIGS[sys.argv[2] if len(sys.argv) > 2 else "pp_map10"])
-    B = c["envs"]
+    B = int(os.environ.get("ENVS", c["envs"]))
     env = E.GridEnvBatch(c["scenario"], bench.env_params(c), B, device="cuda:0", seed=1)
     spec = E.EnvSpec(E._Box(np.zeros(env.d * env.N), np.ones(env.d * env.N)), E._Discrete(5))
     pol = nets.CommCategoricalMLPPolicy(spec, n_agents=env.N, device="cuda:0")
