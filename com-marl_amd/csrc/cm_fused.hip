@@ -21,26 +21,29 @@ bool policy_h_enabled();                                 // cm_policy_h.hip: f16
 
 // POL selects the policy body: 0 = cm_policy_mfma_dev.h (all f32), 1 = cm_policy_h_dev.h (f16-split dense layers).  Both
 // forms take the workgroup's dynamic LDS block; `act` = the sampled actions behind the policy tiles.
-template <int POL, int KPAD, int MAXMK>
+template <int POL, int KPAD, int MAXMK, bool FULL = false>
 __device__ __forceinline__ void policy_body(const mf::FwdArgs &a, const mf::TrunkW &tw, const mf::PolHead &ph, const mh::TrunkH &twh,
                                             const mh::PolHeadH &phh, float *lds, int32_t *act) {
     if constexpr (POL == 0) mf::fwd_body<0, KPAD, MAXMK>(a, tw, ph, mf::CritHead{}, lds, blockIdx.x, act);
-    else mh::fwd_body_h<0, KPAD, MAXMK, 4, false>(a, twh, phh, mh::CritHeadH{}, reinterpret_cast<unsigned char *>(lds), blockIdx.x, act);
+    else mh::fwd_body_h<0, KPAD, MAXMK, 4, false, false, FULL>(a, twh, phh, mh::CritHeadH{}, reinterpret_cast<unsigned char *>(lds), blockIdx.x, act);
 }
 
-template <int SCEN, int LPE, int KPAD, int MAXMK, int POL>
+// FULL: the constant-shape build for teams of 4 with every workgroup full (8 envs, S % 8 == 0) - team size, rows and
+// the LDS map are compile-time constants in the policy body (cm_policy_h_dev.h) and the env count here.
+template <int SCEN, int LPE, int KPAD, int MAXMK, int POL, bool FULL = false>
 __global__ __launch_bounds__(mf::TPB) void rollout_step_kernel(mf::FwdArgs a, mf::TrunkW tw, mf::PolHead ph, mh::TrunkH twh,
                                                                mh::PolHeadH phh, EnvDev p, cm_rng_tape tape, cm_step_out out,
                                                                int act_off) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     int32_t *act = reinterpret_cast<int32_t *>(lds + act_off);           // [EPB*N] sampled actions, behind the policy tiles
-    policy_body<POL, KPAD, MAXMK>(a, tw, ph, twh, phh, lds, act);
+    policy_body<POL, KPAD, MAXMK, FULL>(a, tw, ph, twh, phh, lds, act);
     __syncthreads();                                                     // actions visible; the policy tiles are dead
     const int tx = thread_x(), grp = tx / LPE;
-    const int envs = min(a.EPB, a.S - (int)blockIdx.x * a.EPB);
+    const int EPBc = FULL ? 8 : a.EPB;
+    const int envs = FULL ? 8 : min(a.EPB, a.S - (int)blockIdx.x * a.EPB);
     if ((tx & ~63) / LPE >= envs) return;                               // a wave with no env of its own (the env body syncs wave-locally)
     const bool live = grp < envs;
-    env_body<SCEN, LPE>(p, nullptr, act + (live ? grp : 0) * p.N, tape, out, 0, grp, blockIdx.x * a.EPB + (live ? grp : 0), live, 0);
+    env_body<SCEN, LPE>(p, nullptr, act + (live ? grp : 0) * p.N, tape, out, 0, grp, blockIdx.x * EPBc + (live ? grp : 0), live, 0);
 }
 
 // Persistent form: the workgroup keeps its envs for n_steps consecutive steps (policy -> env -> policy ...), pointers
@@ -139,6 +142,21 @@ static int launch_fused(mf::FwdArgs a, const mf::TrunkW &tw, const mf::PolHead &
                            tw, ph, twh, phh, d, out, *chunk, (int)pol_floats);
         CM_HIP(hipGetLastError());
         return CM_OK;
+    }
+    if constexpr (MAXMK < 0 && POL == 1) {
+        static const bool full_on = [] { const char *e = getenv("COMMARL_FWD_FULL"); return !(e && e[0] == '0'); }();
+        if (full_on && a.EPB == 8 && a.S % 8 == 0) {
+            static bool attr_set_f = false;
+            if (!attr_set_f) {
+                CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_step_kernel<SCEN, LPE, KPAD, MAXMK, POL, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr_set_f = true;
+            }
+            hipLaunchKernelGGL((rollout_step_kernel<SCEN, LPE, KPAD, MAXMK, POL, true>), dim3(blocks), dim3(mf::TPB), lds,
+                               (hipStream_t)stream, a, tw, ph, twh, phh, d, t, out, (int)pol_floats);
+            CM_HIP(hipGetLastError());
+            return CM_OK;
+        }
     }
     hipLaunchKernelGGL((rollout_step_kernel<SCEN, LPE, KPAD, MAXMK, POL>), dim3(blocks), dim3(mf::TPB), lds, (hipStream_t)stream, a, tw,
                        ph, twh, phh, d, t, out, (int)pol_floats);

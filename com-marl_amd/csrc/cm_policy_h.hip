@@ -20,6 +20,13 @@ __global__ __launch_bounds__(64 * NW) void fwd_h_kernel(FwdArgs a, TrunkH tw, Po
     fwd_body_h<HEAD, KH, MAXMK, NW>(a, tw, ph, chd, lds_h, blockIdx.x, nullptr);
 }
 
+// teams of 4, every workgroup full (n_samples a multiple of 8): the constant-shape build
+template <int HEAD, int KH>
+__global__ __launch_bounds__(256) void fwd_h_full_kernel(FwdArgs a, TrunkH tw, PolHeadH ph, CritHeadH chd) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_h[];
+    fwd_body_h<HEAD, KH, -1, 4, true, false, true>(a, tw, ph, chd, lds_h, blockIdx.x, nullptr);
+}
+
 // Teams of 4 at TRAINING batch sizes (tens of thousands of workgroups): the same body with late weight fetches, held to
 // three waves per SIMD (<= 168 VGPRs) so that three workgroups share a CU instead of two - the rollout's 512 workgroups
 // cannot use a third slot, a 34 k-workgroup grid can.
@@ -51,6 +58,17 @@ static int launch_h(FwdArgs a, const TrunkH &tw, const PolHeadH &ph, const CritH
                 attr3 = true;
             }
             hipLaunchKernelGGL((fwd_h_occ3_kernel<HEAD, KH>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, a, tw, ph, chd);
+            CM_HIP(hipGetLastError());
+            return CM_OK;
+        }
+        static const bool full_on = [] { const char *e = getenv("COMMARL_FWD_FULL"); return !(e && e[0] == '0'); }();
+        if (full_on && a.EPB == 8 && a.S % 8 == 0) {
+            static bool attrf = false;
+            if (!attrf) {
+                CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fwd_h_full_kernel<HEAD, KH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attrf = true;
+            }
+            hipLaunchKernelGGL((fwd_h_full_kernel<HEAD, KH>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, a, tw, ph, chd);
             CM_HIP(hipGetLastError());
             return CM_OK;
         }

@@ -411,7 +411,9 @@ __host__ __device__ inline LdsMap lds_map(int rows_cap, int epb, int N, int mode
 // ahead: fewer live registers, for the high-occupancy build that training-size grids use (cm_policy_h.hip)
 #define CM_EARLY(x) do { if constexpr (!LATE) { x; } } while (0)
 #define CM_JIT(x) do { if constexpr (LATE) { x; } } while (0)
-template <int HEAD, int KH, int MAXMK, int NW = 4, bool SAVES = true, bool LATE = false>
+// FULL (teams of 4 only) = every workgroup of the launch holds 8 whole envs (32 rows, 2 row tiles): team size, row counts
+// and the LDS map become compile-time constants and the ragged-tile branches of every layer fold away
+template <int HEAD, int KH, int MAXMK, int NW = 4, bool SAVES = true, bool LATE = false, bool FULL = false>
 __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, const PolHeadH &ph, const CritHeadH &chd,
                                            unsigned char *lds, int blk, int32_t *act_lds) {
     constexpr int TPBW = 64 * NW, NG = 4 * NW;
@@ -421,11 +423,13 @@ __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, c
     constexpr bool big = MAXMK > 0;
     const int tid = thread_x(), wave = tid >> 6, lane = tid & 63;
     const bool sv_on = SAVES && a.sv_on;
-    const int N = a.N, L = a.L, NN = N * N, NP = N | 1;
-    const int s0 = blk * a.EPB;
-    const int envs = min(a.EPB, a.S - s0);
-    const int rows = envs * N, rows_cap = (a.EPB * N + 15) & ~15, RT = (rows + 15) >> 4;
-    const LdsMap lm = lds_map(rows_cap, a.EPB, N, quad_path ? -1 : (big ? 1 : 0));
+    static_assert(!FULL || MAXMK < 0, "full-workgroup constants are those of the teams-of-4 path");
+    const int N = quad_path ? 4 : a.N, L = a.L, NN = N * N, NP = N | 1;
+    const int EPBc = FULL ? 8 : a.EPB;
+    const int s0 = blk * EPBc;
+    const int envs = FULL ? 8 : min(a.EPB, a.S - s0);
+    const int rows = envs * N, rows_cap = (EPBc * N + 15) & ~15, RT = (rows + 15) >> 4;
+    const LdsMap lm = lds_map(rows_cap, EPBc, N, quad_path ? -1 : (big ? 1 : 0));
     const Planes Ap = planes_at(lds + lm.r1, rows_cap, 128);
     const Planes Ep = planes_at(lds + lm.ep, rows_cap, 64);
     const Planes Hp = planes_at(lds + lm.hp, rows_cap, 64);
@@ -653,7 +657,7 @@ __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, c
             // HWt feature row (Q in T is dead: the scores are done) and the A tile's columns the build loop never reaches
             constexpr int JBZ = (MAXMK == 25 || MAXMK == 15) ? 5 : 8;
             const int Kp0 = (N + 31) & ~31, ks0 = Kp0 + SHP, pad = Kp0 - N;
-            h16 *zh = reinterpret_cast<h16 *>(lds + lm.t), *zl = zh + (size_t)a.EPB * EMB * ks0;
+            h16 *zh = reinterpret_cast<h16 *>(lds + lm.t), *zl = zh + (size_t)EPBc * EMB * ks0;
             for (int k = tid; k < envs * EMB * pad; k += TPBW) {
                 const int fe = k / pad, j = N + (k - fe * pad);
                 zh[(size_t)fe * ks0 + j] = (h16)0.0f; zl[(size_t)fe * ks0 + j] = (h16)0.0f;
@@ -690,7 +694,7 @@ __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, c
             }
             // large teams: aggregation on the f16 pipe as well - H.Wg_l as transposed planes, the A tile as planes
             const int Kp = (N + 31) & ~31, KBQ = Kp >> 5, kstride = Kp + SHP;
-            h16 *hwt_hi = reinterpret_cast<h16 *>(lds + lm.t), *hwt_lo = hwt_hi + (size_t)a.EPB * EMB * kstride;
+            h16 *hwt_hi = reinterpret_cast<h16 *>(lds + lm.t), *hwt_lo = hwt_hi + (size_t)EPBc * EMB * kstride;
             const Planes Am = planes_at(lds + lm.r1, rows_cap, Kp);                             // A tile [rows][Kp] over R1
             if (big) l_sq.run_hwt(Hin, hwt_hi, hwt_lo, kstride, N, rows, envs, RT, wave, lane);  // H.Wg_l -> HWt planes in T
             else l_sq.template run<false, OUT_F32>(Hin, Hin, HW, SF, RT, wave, lane);           // H.Wg_l -> f32 in T
