@@ -208,6 +208,13 @@ static int rollout_impl(cm_env_t h, const cm_policy_weights *w, const float *obs
         const uint4 *Q = reinterpret_cast<const uint4 *>(P + lo.total);
         const mh::TrunkH twh{ Q + lh.enc1, w->enc_b1, Q + lh.enc2, w->enc_b2, Q + lh.attn, Q + lh.gcn, w->gcn_b };
         const mh::PolHeadH phh{ Q + lh.x1, w->hd_b1, Q + lh.h2, w->hd_b2, Q + lh.h3, w->hd_b3, Q + lh.h4, w->hd_b4, w->n_act };
+        // teams of 4: 8 envs per workgroup.  With 32 lanes per env the env phase occupies all four waves (16 lanes leave two of
+        // them idle): its lane-parallel loops (observation emission, tile rebuild) halve - 28.5 -> 27.4 us per step at the
+        // headline config.  The stand-alone env kernel keeps the handle's own choice (16: more envs per wave); the env body
+        // is bit-identical at every width (tests/test_hip_scale_parity.py).  COMMARL_FUSED_LPE=16 for the A/B.
+        static const int fused_lpe = [] { const char *e = getenv("COMMARL_FUSED_LPE"); return e ? atoi(e) : 32; }();
+        if (d.scen == CM_PP && d.lpe <= 32 && kh == 32 && quad && fused_lpe == 32 && !chunk)
+            return launch_fused<CM_PP, 32, 32, -1, 1>(a, tw, ph, twh, phh, h, t, *out, stream, chunk);
         if (d.scen == CM_PP && d.lpe == 16 && kh == 32 && quad) return launch_fused<CM_PP, 16, 32, -1, 1>(a, tw, ph, twh, phh, h, t, *out, stream, chunk);
         if (d.scen == CM_PP && d.lpe == 16 && kh == 32 && mk == 0) return launch_fused<CM_PP, 16, 32, 0, 1>(a, tw, ph, twh, phh, h, t, *out, stream, chunk);
         if (d.scen == CM_CO && d.lpe == 64 && kh == 96 && mk == 0) return launch_fused<CM_CO, 64, 96, 0, 1>(a, tw, ph, twh, phh, h, t, *out, stream, chunk);
