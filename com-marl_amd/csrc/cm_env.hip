@@ -226,6 +226,7 @@ extern "C" int cm_env_create(const cm_env_cfg *cfg, cm_env_t *out) {
     }
     h->lds_bytes = (size_t)d.lds_env * (WAVE / d.lpe);
     { const char *e = getenv("COMMARL_ENV_STOP"); d.stop = e ? atoi(e) : 0; }
+    { const char *e = getenv("COMMARL_ENV_SMALL"); d.no_small = (e && e[0] == '0') ? 1 : 0; }
     d.rcp_d = 1.0f / (float)d.d; d.rcp_W = 1.0f / (float)d.W; d.rcp_N = 1.0f / (float)d.N;
     d.rcp_WW = 1.0f / (float)(d.W * d.W); d.rcp_NN = 1.0f / (float)(d.N * d.N);
     e = hipDeviceSynchronize();
@@ -296,6 +297,14 @@ static int launch(cm_env_t h, const int32_t *actions, const cm_rng_tape *tape, c
     else { if (d.lpe == 16) CM_LAUNCH(CM_CO, 16); else if (d.lpe == 32) CM_LAUNCH(CM_CO, 32); else CM_LAUNCH(CM_CO, 64); }
 #undef CM_LAUNCH
     CM_HIP(hipGetLastError());
+    if (d.stop < 0) {                                                    // diagnostic: phase clocks of workgroup 0 (ENV_PROBE)
+        unsigned long long h_probe[16];
+        CM_HIP(hipStreamSynchronize(st));
+        CM_HIP(hipMemcpyFromSymbol(h_probe, HIP_SYMBOL(g_env_probe), sizeof(h_probe)));
+        fprintf(stderr, "[env probe] clk since entry:");
+        for (int i = 1; i < 10; ++i) fprintf(stderr, " p%d=%lld", i, (long long)(h_probe[i] - h_probe[0]));
+        fprintf(stderr, "\n");
+    }
     return CM_OK;
 }
 

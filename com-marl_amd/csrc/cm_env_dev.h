@@ -17,6 +17,11 @@ constexpr int PAR_AGENTS_MIN = 16;  // teams larger than this resolve their move
 // the data-dependent reset loop once several waves share a workgroup.)
 #define ENV_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
+// Diagnostic (COMMARL_ENV_STOP=-1): shader-clock stamps of thread 0 of workgroup 0 at the phase boundaries of one step;
+// the launching translation unit prints the differences (cm_env.hip).
+static __device__ unsigned long long g_env_probe[16];
+#define ENV_PROBE(i) do { if (p.stop < 0 && blockIdx.x == 0 && thread_x() == 0) g_env_probe[i] = __builtin_amdgcn_s_memtime(); } while (0)
+
 __device__ __forceinline__ int dr_of(int a) { return a == 0 ? 1 : (a == 2 ? -1 : 0); }   // predator_prey.py:244-253
 __device__ __forceinline__ int dc_of(int a) { return a == 1 ? -1 : (a == 3 ? 1 : 0); }
 __device__ __forceinline__ bool in_grid(int r, int c, int S) { return (unsigned)r < (unsigned)S && (unsigned)c < (unsigned)S; }
@@ -466,6 +471,167 @@ __device__ __forceinline__ MoveOut agents_parallel(const EnvDev &p, const Lds l,
 // dynamic LDS block, `act_lds` = optional [N] action bytes already in LDS for this env (fused rollout kernel), else
 // the actions come from `actions` in HBM.  All synchronisation is wave-local (ENV_SYNC), so the body runs unchanged
 // inside the single-wave env kernel and inside the 4-wave fused rollout workgroup.
+// ---------------------------------------------------------------------------------------
+// Small PP teams (n_agents, n_preys <= R <= 8, several envs per wave): the order-dependent part of the step with every
+// position in registers.  The tile walk below costs three dependent LDS round trips per agent / prey (action -> position
+// -> target cell, then the commit) - 11.5 k of the env step's 25 k clocks at the headline shape (ENV_PROBE).  Here every
+// lane of an env's group holds ALL its agents and preys and replays the sequential loops redundantly: "is the target
+// cell empty" becomes <= 2R register compares (a cell holds at most one entity), "predators / preys next to (r, c)" a
+// count of entities at Manhattan distance 1 (exactly the four bounds-checked neighbour cells of count_adj).  Only the
+// prey trials stay one lane per prey (Philox per prey), their results crossing lanes once through LDS.
+// In: AR / AC / ACT / PR / PC / ALV staged in LDS, tile all C_EMPTY.  Out: the same arrays and the tile at their
+// end-of-step values, as the tile walk leaves them.  Reference lines as in env_body below.
+// ---------------------------------------------------------------------------------------
+struct SmallOut { int moving, capture, penalty, wsum; bool tape_short, any_alive; };
+
+// Straight-line code throughout (selects, no short-circuit operators: hipcc turns every `&&` on lane data into an
+// exec-mask branch), and no long-lived booleans (each one is a 64-bit lane mask in scalar registers: an `alive[R]` array
+// spills them).  Coordinates are held +1 so that a target one step outside the grid stays non-negative and |a - b| is one
+// v_sad_u32; absent entities AND dead preys sit at (100, 100): never equal to, never next to anything real, so liveness
+// needs no flag of its own.
+constexpr int GONE = 100;
+// |a - b| + c in one instruction (hipcc expands __usad into max / min / sub / add)
+__device__ __forceinline__ unsigned sad(unsigned a, unsigned b, unsigned c) {
+    unsigned d;
+    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ unsigned sad0(unsigned a, unsigned b) {
+    unsigned d;
+    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ unsigned dist1(int r0, int c0, int r1, int c1) {  // Manhattan distance
+    return sad((unsigned)c0, (unsigned)c1, sad0((unsigned)r0, (unsigned)r1));
+}
+// 1 if no entity of either layer stands on (r, c)
+template <int R>
+__device__ __forceinline__ int cell_free(const int (&ar)[R], const int (&ac)[R], const int (&pr)[R], const int (&pc)[R], int r, int c) {
+    unsigned m = 1u;
+#pragma unroll
+    for (int k = 0; k < R; ++k) m = min(m, min(dist1(ar[k], ac[k], r, c), dist1(pr[k], pc[k], r, c)));
+    return (int)m;
+}
+// number of entities of one layer at distance exactly 1 from (r, c)
+template <int R>
+__device__ __forceinline__ int next_to(const int (&er)[R], const int (&ec)[R], int r, int c) {
+    int n = 0;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        unsigned e;                                    // |d - 1|: 0 exactly at distance 1
+        asm("v_sad_u32 %0, %1, 1, 0" : "=v"(e) : "v"(dist1(er[k], ec[k], r, c)));
+        n += 1 - (int)min(e, 1u);
+    }
+    return n;
+}
+
+template <int LPE, int R>
+__device__ __forceinline__ SmallOut pp_small_step(const EnvDev &p, const Lds l, const Rng &rng, const cm_rng_tape &tape, int b,
+                                                  const Grp<LPE> g) {
+    const int N = p.N, M = p.M, S = p.S, sl = g.sl;
+    int ar[R], ac[R], act[R], pr[R], pc[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        ar[i] = GONE; ac[i] = GONE; act[i] = 4; pr[i] = GONE; pc[i] = GONE;
+        if (i < N) { ar[i] = AR(l, i) + 1; ac[i] = AC(l, i) + 1; act[i] = ACT(l, i); }
+        if (i < M) { const int alive = ALV(l, i); pr[i] = alive ? PR(l, i) + 1 : GONE; pc[i] = alive ? PC(l, i) + 1 : GONE; }
+    }
+    const bool mine = sl < M;                          // this lane's prey for the trials: start-of-step values
+    int my_r = GONE, my_c = GONE;
+    if (mine) { const int alive = ALV(l, sl); my_r = alive ? PR(l, sl) + 1 : GONE; my_c = alive ? PC(l, sl) + 1 : GONE; }
+    const bool taped = p.rng_mode == CM_RNG_TAPE;
+    // the prey's first four trial words depend on nothing the step computes: issued under the LDS latency
+    u32x4 x0 = { 0, 0, 0, 0 };
+    if (mine && !taped) x0 = rng.at(SITE_PREY, (uint32_t)(2 * sl));
+    ENV_SYNC();
+
+    SmallOut o{ 0, 0, 0, 0, false, false };
+    // ---- agents move in index order (predator_prey.py:497-500, :240-261) ----
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int a = act[i];
+        const int active = (i < N) & (a != 4);         // pseudo-action 5 (faulty agent): target = own cell, rejected by k == i
+        o.moving += active;
+        const int nr = ar[i] + dr_of(a), nc = ac[i] + dc_of(a);
+        const int ok = active & ((unsigned)(nr - 1) < (unsigned)S) & ((unsigned)(nc - 1) < (unsigned)S) & cell_free<R>(ar, ac, pr, pc, nr, nc);
+        ar[i] = ok ? nr : ar[i]; ac[i] = ok ? nc : ac[i];
+    }
+    // ---- per-prey work against the (now static) agent layer: one lane per prey (:396-407) ----
+    {
+        const int my_alive = my_r != GONE;
+        const int cnt = next_to<R>(ar, ac, my_r, my_c);                      // 0 for a dead prey
+        int mv = 4;
+        int found = (my_alive ^ 1) | ((p.load == 2) & (cnt >= 2));          // dead, or captured this step: no trial
+        if (taped) {
+            for (int t = 0; t < 5 && !found; ++t) {
+                const int m = tape.prey[((size_t)b * M + sl) * 5 + t];
+                if (m > 4) { mv = 4 | 8; break; }      // recorded tape ended: only legal if prey gets captured
+                if (next_to<R>(ar, ac, my_r + dr_of(m), my_c + dc_of(m)) == 0) { mv = m; found = 1; }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {              // first of <= 5 draws whose target has no predator neighbour
+                const int m = prey_move_from_u32(pick(x0, t));
+                const int ok = (next_to<R>(ar, ac, my_r + dr_of(m), my_c + dc_of(m)) == 0) & (found ^ 1);
+                mv = ok ? m : mv; found |= ok;
+            }
+            if (!found) {                              // fifth draw: second Philox call, rare
+                const u32x4 x1 = rng.at(SITE_PREY, (uint32_t)(2 * sl + 1));
+                const int m = prey_move_from_u32(x1.x);
+                mv = next_to<R>(ar, ac, my_r + dr_of(m), my_c + dc_of(m)) == 0 ? m : mv;
+            }
+        }
+        if (mine) { PCNT(l, sl) = (uint8_t)cnt; PMV(l, sl) = (uint8_t)mv; }
+    }
+    // prey_watching (:419-423): agents 4-adjacent to a live prey (prey layer at start-of-phase positions)
+    int my_ar = GONE, my_ac = GONE;                    // this lane's agent, for the count and the write-back
+#pragma unroll
+    for (int i = 0; i < R; ++i) { my_ar = sl == i ? ar[i] : my_ar; my_ac = sl == i ? ac[i] : my_ac; }
+    o.wsum = g.count(next_to<R>(pr, pc, my_ar, my_ac) != 0);                 // absent agents sit next to nothing
+    ENV_SYNC();
+    int pcnt[R], pmv[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) { pcnt[j] = 0; pmv[j] = 4; if (j < M) { pcnt[j] = PCNT(l, j); pmv[j] = PMV(l, j); } }
+    ENV_SYNC();
+    // ---- captures + prey moves in index order (:416-432 / :460-478, :276-301) ----
+    int tshort = 0, alive_any = 0;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const int r = pr[j], c = pc[j], cnt = pcnt[j], mvb = pmv[j];
+        const int alive = r != GONE;
+        int need = p.load;
+        if (p.load != 2) {                                                       // reward_individual :467-470 (uniform branch)
+            const int on_r = (r == 1) | (r == S), on_c = (c == 1) | (c == S);
+            const int adj = (on_r & on_c) ? 2 : ((on_r | on_c) ? 3 : p.load);    // __create_edges :123-144
+            const int avail = adj - next_to<R>(pr, pc, r, c);
+            need = p.load < avail ? p.load : avail;
+        }
+        const int hit = alive & (cnt >= 1), captured = hit & (need <= cnt);
+        o.capture += captured; o.penalty += hit & (captured ^ 1);
+        const int stays = alive & (captured ^ 1);                                // :301 otherwise
+        tshort |= stays & ((mvb >> 3) & 1);
+        const int mv = mvb & 7;
+        const int nr = r + dr_of(mv), nc = c + dc_of(mv);
+        const int ok = stays & (mv != 4) & ((unsigned)(nr - 1) < (unsigned)S) & ((unsigned)(nc - 1) < (unsigned)S) &
+                       cell_free<R>(ar, ac, pr, pc, nr, nc);
+        pr[j] = stays ? (ok ? nr : r) : GONE; pc[j] = stays ? (ok ? nc : c) : GONE;
+        alive_any |= stays;
+    }
+    o.tape_short = tshort != 0; o.any_alive = alive_any != 0;
+    // ---- end-of-step state back to LDS: lane i its agent and its prey, then the tile marks ----
+    int my_pr = GONE, my_pc = GONE;
+#pragma unroll
+    for (int j = 0; j < R; ++j) { my_pr = sl == j ? pr[j] : my_pr; my_pc = sl == j ? pc[j] : my_pc; }
+    if (sl < N) { AR(l, sl) = (int16_t)(my_ar - 1); AC(l, sl) = (int16_t)(my_ac - 1); Gc(l, (my_ar - 1) * S + my_ac - 1) = C_AGENT; }
+    if (mine) {
+        const bool my_al = my_pr != GONE;
+        ALV(l, sl) = (uint8_t)my_al;
+        if (my_al) { PR(l, sl) = (int16_t)(my_pr - 1); PC(l, sl) = (int16_t)(my_pc - 1); Gc(l, (my_pr - 1) * S + my_pc - 1) = C_PREY; }
+    }
+    ENV_SYNC();
+    return o;
+}
+
 template <int SCEN, int LPE>
 __device__ __forceinline__ void env_body(const EnvDev &p, const int32_t *__restrict__ actions, const int32_t *act_lds,
                                          const cm_rng_tape &tape, const cm_step_out &out, int reset_only, int grp, int b_raw,
@@ -474,6 +640,7 @@ __device__ __forceinline__ void env_body(const EnvDev &p, const int32_t *__restr
     const int tx = thread_x();
     g.sub = (tx & (WAVE - 1)) / LPE; g.sl = tx % LPE;
     const int sl = g.sl;
+    ENV_PROBE(0);
     const bool valid = grp_live && b_raw < p.B;
     const int b = valid ? b_raw : p.B - 1;            // idle groups shadow the last env and never commit
     const Lds l = make_lds(p.S, p.N, p.M, lds_base + p.lds_env * grp, p.status);
@@ -518,12 +685,18 @@ __device__ __forceinline__ void env_body(const EnvDev &p, const int32_t *__restr
     if (env_bad && sl == 0 && valid) raise(p, CM_ERR_ACTION);
     const bool commit = valid && !env_bad;
     ENV_SYNC();
+    ENV_PROBE(1);
     if (p.stop == 1) return;
-    for (int i = sl; i < N; i += LPE) Gc(l, AR(l, i) * S + AC(l, i)) = C_AGENT;
-    if (SCEN == CM_PP)
-        for (int j = sl; j < M; j += LPE) if (ALV(l, j)) Gc(l, PR(l, j) * S + PC(l, j)) = C_PREY;
-    ENV_SYNC();
+    // small PP teams keep their positions in registers (pp_small_step) and mark the tile once, at the end of the step
+    const bool small = SCEN == CM_PP && LPE < 64 && N <= 8 && M <= 8 && M <= LPE && !p.no_small;
+    if (!small) {
+        for (int i = sl; i < N; i += LPE) Gc(l, AR(l, i) * S + AC(l, i)) = C_AGENT;
+        if (SCEN == CM_PP)
+            for (int j = sl; j < M; j += LPE) if (ALV(l, j)) Gc(l, PR(l, j) * S + PC(l, j)) = C_PREY;
+        ENV_SYNC();
+    }
 
+    ENV_PROBE(2);
     if (p.stop == 2) return;
     int step_count = p.step_count[b] + 1;
     int succ = p.success[b];
@@ -534,6 +707,14 @@ __device__ __forceinline__ void env_body(const EnvDev &p, const int32_t *__restr
     if (SCEN == CM_PP) {
         // ---- agents move in index order (predator_prey.py:497-500, :240-261) ----
         int moving = 0;
+        int capture = 0, penalty = 0, wsum = 0;
+        bool tape_short = false, any_alive = false;
+        if (LPE < 64 && small) {
+            const SmallOut so = (N <= 4 && M <= 4) ? pp_small_step<LPE, 4>(p, l, rng, tape, b, g) : pp_small_step<LPE, 8>(p, l, rng, tape, b, g);
+            moving = so.moving; capture = so.capture; penalty = so.penalty; wsum = so.wsum; tape_short = so.tape_short;
+            any_alive = so.any_alive;
+            ENV_PROBE(5);
+        } else {
         if (N > PAR_AGENTS_MIN) moving = agents_parallel<SCEN, LPE>(p, l, g).moving;      // large teams: parallel resolution
         else for (int i = 0; i < N; ++i) {                                                // small teams: group-uniform loop
             const int a = ACT(l, i);
@@ -548,9 +729,8 @@ __device__ __forceinline__ void env_body(const EnvDev &p, const int32_t *__restr
             if (mv && sl == 0) { Gc(l, r * S + c) = C_EMPTY; Gc(l, nr * S + nc) = C_AGENT; AR(l, i) = (int16_t)nr; AC(l, i) = (int16_t)nc; }
             ENV_SYNC();
         }
+        ENV_PROBE(3);
         if (p.stop == 3) return;
-        int capture = 0, penalty = 0, wsum = 0;
-        bool tape_short = false;
         if (LPE == 64) {
         // ---- one wave per env: the per-prey inputs of the sequential loop (alive, position, predator count, chosen
         // move - all start-of-phase values, nothing an earlier prey can change) stay in the registers of the lane that
@@ -590,6 +770,7 @@ __device__ __forceinline__ void env_body(const EnvDev &p, const int32_t *__restr
             wsum += g.count(w);
         }
         ENV_SYNC();
+        ENV_PROBE(4);
         if (p.stop == 4) return;
         for (int j = 0; j < M; ++j) {
             const int lanej = j & (LPE - 1), qj = j >> 6;
@@ -649,6 +830,7 @@ __device__ __forceinline__ void env_body(const EnvDev &p, const int32_t *__restr
             }
             PCNT(l, j) = (uint8_t)cnt; PMV(l, j) = (uint8_t)mv;
         }
+        ENV_PROBE(8);
         // prey_watching (:419-423): agents 4-adjacent to a live prey (prey layer still at start-of-phase positions)
         for (int i0 = 0; i0 < N; i0 += LPE) {
             const int i = i0 + sl;
@@ -656,6 +838,7 @@ __device__ __forceinline__ void env_body(const EnvDev &p, const int32_t *__restr
             wsum += g.count(w);
         }
         ENV_SYNC();
+        ENV_PROBE(4);
         if (p.stop == 4) return;
         // ---- captures + prey moves in index order (:416-432 / :460-478, :276-301): group-uniform loop ----
         for (int j = 0; j < M; ++j) {
@@ -692,6 +875,9 @@ __device__ __forceinline__ void env_body(const EnvDev &p, const int32_t *__restr
             ENV_SYNC();
         }
         }   // LPE != 64
+        for (int j0 = 0; j0 < M; j0 += LPE) any_alive |= g.any(j0 + sl < M && ALV(l, j0 + sl));
+        ENV_PROBE(5);
+        }   // tile walk
         if (p.stop == 5) return;
         if (tape_short && sl == 0 && commit) raise(p, CM_ERR_TAPE_PREY);
         // reward in f64 exactly as the Python expression evaluates (:434 / :480); no FMA contraction (build flag)
@@ -700,8 +886,6 @@ __device__ __forceinline__ void env_body(const EnvDev &p, const int32_t *__restr
         reward = p.rew_lut[capture] + p.rew_lut[(M + 1) + moving];
         if (p.load == 2) reward = reward + p.penalty * (double)penalty;
         det0 = capture; det1 = moving; det2 = penalty; det4 = wsum;
-        bool any_alive = false;
-        for (int j0 = 0; j0 < M; j0 += LPE) any_alive |= g.any(j0 + sl < M && ALV(l, j0 + sl));
         if (o.prey_alive && commit) for (int j = sl; j < M; j += LPE) o.prey_alive[(size_t)b * M + j] = ALV(l, j);
         done = (step_count >= p.max_steps) || !any_alive;               // :511-517
         if (done) succ = any_alive ? 0 : 1;
@@ -759,10 +943,12 @@ __device__ __forceinline__ void env_body(const EnvDev &p, const int32_t *__restr
         p.rng_step[b] = rng.step + 1;
     }
     ENV_SYNC();
+    ENV_PROBE(6);
     if (p.stop == 6) return;
     // auto-reset (:36-43): groups whose env finished re-spawn and emit the reset observation
     do_reset<SCEN, LPE>(p, l, rng, tape, b, g, done != 0);
     if (done) step_count = 0;
+    ENV_PROBE(7);
     if (!commit || p.stop == 7) return;
     if (sl == 0) {
         if (done && SCEN == CM_CO) p.total_capture[b] = 0;
@@ -774,6 +960,7 @@ __device__ __forceinline__ void env_body(const EnvDev &p, const int32_t *__restr
     // workgroup's waves after this wave has left the state in LDS; hand over (step count, slot, Philox step)
     if (defer) { if (sl == 0) { defer[1] = step_count; defer[2] = done ? 1 : 0; defer[3] = (int)rng.step; defer[0] = 1; } return; }
     emit<SCEN, LPE>(p, l, rng, tape, o, b, g, step_count, done ? 1 : 0);
+    ENV_PROBE(9);
 }
 
 

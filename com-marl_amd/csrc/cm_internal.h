@@ -34,6 +34,7 @@ struct EnvDev {
     int ge_flags;             // cm_env_cfg.ge_flags (bit 0: one GE transition per env step; bits 1-2: initial state)
     int lpe, lds_env;         // lanes per env (16/32/64) and LDS bytes per env
     int stop;                 // diagnostic (COMMARL_ENV_STOP): return after phase `stop`; 0 = run everything
+    int no_small;             // COMMARL_ENV_SMALL=0: tile walk also for small PP teams (A/B of pp_small_step)
     float rcp_d, rcp_W, rcp_N, rcp_WW, rcp_NN;   // float reciprocals for the exact fast division in the emit loops
     float ploss, pgb, pbg;
     double cap_rew, step_cost, move_cost, penalty, lazy, revisit, final_reward;
