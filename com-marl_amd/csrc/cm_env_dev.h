@@ -20,7 +20,7 @@ constexpr int PAR_AGENTS_MIN = 16;  // teams larger than this resolve their move
 // Diagnostic (COMMARL_ENV_STOP=-1): shader-clock stamps of thread 0 of workgroup 0 at the phase boundaries of one step;
 // the launching translation unit prints the differences (cm_env.hip).
 static __device__ unsigned long long g_env_probe[16];
-#define ENV_PROBE(i) do { if (p.stop < 0 && blockIdx.x == 0 && thread_x() == 0) g_env_probe[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define ENV_PROBE(i) do { asm volatile("; ENV_PROBE " #i); if (p.stop < 0 && blockIdx.x == 0 && thread_x() == 0) g_env_probe[i] = __builtin_amdgcn_s_memtime(); } while (0)
 
 __device__ __forceinline__ int dr_of(int a) { return a == 0 ? 1 : (a == 2 ? -1 : 0); }   // predator_prey.py:244-253
 __device__ __forceinline__ int dc_of(int a) { return a == 1 ? -1 : (a == 3 ? 1 : 0); }
@@ -214,13 +214,48 @@ __device__ __forceinline__ void do_reset(const EnvDev &p, const Lds l, const Rng
 // ---------------------------------------------------------------------------------------
 // emission: obs + dist_adj + channels + state write-back
 // ---------------------------------------------------------------------------------------
+// The observation's coordinate / clock entries come from host-built tables (exact reference arithmetic).  Read inside the
+// element loop each is a dependent global load in front of that iteration's store (1.7 k of the emission's 6.6 k clocks at
+// the headline shape); a caller that knows the step early passes them in registers instead: lane s of an env's group holds
+// row[s] and col[s] (grid side <= lanes per env) and the element fetches its entry with a lane shuffle.
+struct ObsTabs { bool held; float row, col, step; };
+
 template <int SCEN, int LPE>
 __device__ __forceinline__ void emit(const EnvDev &p, const Lds l, const Rng rng, const cm_rng_tape &tape,
-                                     const cm_step_out &out, int b, const Grp<LPE> g, int step_count, int slot) {
+                                     const cm_step_out &out, int b, const Grp<LPE> g, int step_count, int slot,
+                                     const ObsTabs tabs = ObsTabs{ false, 0.0f, 0.0f, 0.0f }) {
     const int S = p.S, N = p.N, M = p.M, R = p.R, W = p.W, d = p.d, WW = W * W, sl = g.sl;
     const float rcp_d = p.rcp_d, rcp_W = p.rcp_W, rcp_N = p.rcp_N, rcp_WW = p.rcp_WW, rcp_NN = p.rcp_NN;
     // ---- observations [N*d], lanes stride the flattened row -> coalesced stores ----
-    if (out.obs) {
+    if (out.obs && tabs.held) {
+        float *o = out.obs + (size_t)b * N * d;
+        const int total = N * d;
+        for (int k0 = 0; k0 < total; k0 += LPE) {                       // uniform trip count: every lane takes part in the shuffles
+            const int k = k0 + sl;
+            const bool on = k < total;
+            const int kk = on ? k : 0;
+            const int i = fdiv(kk, d, rcp_d), f = kk - i * d;
+            const int r0 = AR(l, i), c0 = AC(l, i);
+            const float vrow = __shfl(tabs.row, r0, LPE), vcol = __shfl(tabs.col, c0, LPE);
+            float v;
+            if (SCEN == CM_PP) {
+                if (f < 2 * WW) {                                   // get_neighbors (predator_prey.py:173-181)
+                    const int chn = f >= WW, w = f - chn * WW, wr = fdiv(w, W, rcp_W), wc = w - wr * W;
+                    v = (cell(l, r0 - R + wr, c0 - R + wc, S) == (chn ? C_PREY : C_AGENT)) ? 1.0f : 0.0f;
+                } else v = f == 2 * WW ? vrow : (f == 2 * WW + 1 ? vcol : tabs.step);      // (:195-196)
+            } else {
+                if (f < 3 * WW) {                                   // get_local_view (coverage.py:448-480)
+                    const int chn = fdiv(f, WW, rcp_WW), w = f - chn * WW, wr = fdiv(w, W, rcp_W), wc = w - wr * W;
+                    const int rr = r0 - R + wr, cc = c0 - R + wc;
+                    const bool in = in_grid(rr, cc, S);
+                    if (chn == 0) v = (!in || Gc(l, rr * S + cc) == C_WALL) ? 1.0f : 0.0f;
+                    else if (chn == 1) v = (in && Gc(l, rr * S + cc) == C_AGENT) ? 1.0f : 0.0f;
+                    else v = (in && ((VIS(l, rr) >> cc) & 1u)) ? 1.0f : 0.0f;
+                } else v = f == 3 * WW ? vrow : (f == 3 * WW + 1 ? vcol : tabs.step);      // (:206)
+            }
+            if (on) o[k] = v;
+        }
+    } else if (out.obs) {
         float *o = out.obs + (size_t)b * N * d;
         const int total = N * d;
         for (int k = sl; k < total; k += LPE) {
@@ -531,14 +566,19 @@ __device__ __forceinline__ SmallOut pp_small_step(const EnvDev &p, const Lds l, 
     const int N = p.N, M = p.M, S = p.S, sl = g.sl;
     int ar[R], ac[R], act[R], pr[R], pc[R];
 #pragma unroll
-    for (int i = 0; i < R; ++i) {
-        ar[i] = GONE; ac[i] = GONE; act[i] = 4; pr[i] = GONE; pc[i] = GONE;
-        if (i < N) { ar[i] = AR(l, i) + 1; ac[i] = AC(l, i) + 1; act[i] = ACT(l, i); }
-        if (i < M) { const int alive = ALV(l, i); pr[i] = alive ? PR(l, i) + 1 : GONE; pc[i] = alive ? PC(l, i) + 1 : GONE; }
+    for (int i = 0; i < R; ++i) {                      // unconditional reads (index clamped) so that all are in flight together
+        const int ia = i < N ? i : 0, ip = i < M ? i : 0;
+        const int r = AR(l, ia), c = AC(l, ia), a = ACT(l, ia), qr = PR(l, ip), qc = PC(l, ip), alive = ALV(l, ip);
+        ar[i] = i < N ? r + 1 : GONE; ac[i] = i < N ? c + 1 : GONE; act[i] = i < N ? a : 4;
+        pr[i] = ((i < M) & (alive != 0)) ? qr + 1 : GONE; pc[i] = ((i < M) & (alive != 0)) ? qc + 1 : GONE;
     }
     const bool mine = sl < M;                          // this lane's prey for the trials: start-of-step values
-    int my_r = GONE, my_c = GONE;
-    if (mine) { const int alive = ALV(l, sl); my_r = alive ? PR(l, sl) + 1 : GONE; my_c = alive ? PC(l, sl) + 1 : GONE; }
+    int my_r, my_c;
+    {
+        const int ip = mine ? sl : 0;
+        const int qr = PR(l, ip), qc = PC(l, ip), alive = ALV(l, ip);
+        my_r = (mine & (alive != 0)) ? qr + 1 : GONE; my_c = (mine & (alive != 0)) ? qc + 1 : GONE;
+    }
     const bool taped = p.rng_mode == CM_RNG_TAPE;
     // the prey's first four trial words depend on nothing the step computes: issued under the LDS latency
     u32x4 x0 = { 0, 0, 0, 0 };
@@ -556,6 +596,7 @@ __device__ __forceinline__ SmallOut pp_small_step(const EnvDev &p, const Lds l, 
         const int ok = active & ((unsigned)(nr - 1) < (unsigned)S) & ((unsigned)(nc - 1) < (unsigned)S) & cell_free<R>(ar, ac, pr, pc, nr, nc);
         ar[i] = ok ? nr : ar[i]; ac[i] = ok ? nc : ac[i];
     }
+    ENV_PROBE(3);
     // ---- per-prey work against the (now static) agent layer: one lane per prey (:396-407) ----
     {
         const int my_alive = my_r != GONE;
@@ -583,6 +624,7 @@ __device__ __forceinline__ SmallOut pp_small_step(const EnvDev &p, const Lds l, 
         }
         if (mine) { PCNT(l, sl) = (uint8_t)cnt; PMV(l, sl) = (uint8_t)mv; }
     }
+    ENV_PROBE(8);
     // prey_watching (:419-423): agents 4-adjacent to a live prey (prey layer at start-of-phase positions)
     int my_ar = GONE, my_ac = GONE;                    // this lane's agent, for the count and the write-back
 #pragma unroll
@@ -591,8 +633,13 @@ __device__ __forceinline__ SmallOut pp_small_step(const EnvDev &p, const Lds l, 
     ENV_SYNC();
     int pcnt[R], pmv[R];
 #pragma unroll
-    for (int j = 0; j < R; ++j) { pcnt[j] = 0; pmv[j] = 4; if (j < M) { pcnt[j] = PCNT(l, j); pmv[j] = PMV(l, j); } }
+    for (int j = 0; j < R; ++j) {
+        const int jp = j < M ? j : 0;
+        const int cn = PCNT(l, jp), mb = PMV(l, jp);
+        pcnt[j] = j < M ? cn : 0; pmv[j] = j < M ? mb : 4;
+    }
     ENV_SYNC();
+    ENV_PROBE(4);
     // ---- captures + prey moves in index order (:416-432 / :460-478, :276-301) ----
     int tshort = 0, alive_any = 0;
 #pragma unroll
@@ -658,6 +705,15 @@ __device__ __forceinline__ void env_body(const EnvDev &p, const int32_t *__restr
         return;
     }
 
+    const int step_count_in = p.step_count[b];         // requested first: the clock entry below depends on it
+    int succ = p.success[b];
+    // tables the end of the step needs, requested now (ObsTabs; the reward terms likewise: lane s holds rew_lut[s])
+    const bool tabs_held = S <= LPE;
+    const bool rew_held = SCEN == CM_PP && LPE < 64 && (M + 1) + (N + 1) <= LPE;
+    float t_row = 0.0f, t_col = 0.0f, t_step0 = 0.0f;
+    double t_rew = 0.0;
+    if (tabs_held) { const int s0 = sl < S ? sl : S - 1; t_row = p.lut_row[s0]; t_col = p.lut_col[s0]; t_step0 = p.lut_step[0]; }
+    if (rew_held) t_rew = p.rew_lut[sl < (M + 1) + (N + 1) ? sl : 0];
     // ---- load SoA state, rebuild the occupancy tile in LDS ----
     bool bad_action = false;
     for (int i = sl; i < N; i += LPE) {
@@ -698,8 +754,9 @@ __device__ __forceinline__ void env_body(const EnvDev &p, const int32_t *__restr
 
     ENV_PROBE(2);
     if (p.stop == 2) return;
-    int step_count = p.step_count[b] + 1;
-    int succ = p.success[b];
+    int step_count = step_count_in + 1;
+    float t_step = 0.0f;
+    if (tabs_held) t_step = p.lut_step[step_count <= p.max_steps ? step_count : p.max_steps];
     int done = 0;
     double reward;
     int det0 = 0, det1 = 0, det2 = 0, det3 = 0, det4 = 0, det5 = 0;
@@ -883,7 +940,8 @@ __device__ __forceinline__ void env_body(const EnvDev &p, const int32_t *__restr
         // reward in f64 exactly as the Python expression evaluates (:434 / :480); no FMA contraction (build flag)
         // (step + cap*c) + (mc*m)/N [+ pen*p]: the two count-indexed terms come from host tables built with the
         // same f64 operations (no f64 division on the device)
-        reward = p.rew_lut[capture] + p.rew_lut[(M + 1) + moving];
+        if (rew_held) reward = __shfl(t_rew, capture, LPE) + __shfl(t_rew, (M + 1) + moving, LPE);
+        else reward = p.rew_lut[capture] + p.rew_lut[(M + 1) + moving];
         if (p.load == 2) reward = reward + p.penalty * (double)penalty;
         det0 = capture; det1 = moving; det2 = penalty; det4 = wsum;
         if (o.prey_alive && commit) for (int j = sl; j < M; j += LPE) o.prey_alive[(size_t)b * M + j] = ALV(l, j);
@@ -959,7 +1017,7 @@ __device__ __forceinline__ void env_body(const EnvDev &p, const int32_t *__restr
     // wide kernel: the emission (order-independent, the bulk of the instructions for large teams) is done by all the
     // workgroup's waves after this wave has left the state in LDS; hand over (step count, slot, Philox step)
     if (defer) { if (sl == 0) { defer[1] = step_count; defer[2] = done ? 1 : 0; defer[3] = (int)rng.step; defer[0] = 1; } return; }
-    emit<SCEN, LPE>(p, l, rng, tape, o, b, g, step_count, done ? 1 : 0);
+    emit<SCEN, LPE>(p, l, rng, tape, o, b, g, step_count, done ? 1 : 0, ObsTabs{ tabs_held, t_row, t_col, done ? t_step0 : t_step });
     ENV_PROBE(9);
 }
 
