@@ -679,10 +679,74 @@ __device__ __forceinline__ SmallOut pp_small_step(const EnvDev &p, const Lds l, 
     return o;
 }
 
+// Everything the step reads from HBM that does not depend on the actions: a caller with other work in front of the env
+// step (the fused rollout kernel: the whole policy forward) requests it first and hands it over in registers, so the
+// env phase starts without a memory round trip.  One lane = one agent and one prey (teams <= lanes per env).
+struct EnvPre {
+    bool on;
+    uint32_t rng_step;
+    int step_count_in, succ;
+    float t_row, t_col, t_step0, t_step;
+    double t_rew;
+    int ax, ay, px, py;
+    int cond, alive;
+};
+
+template <int SCEN, int LPE>
+__host__ __device__ __forceinline__ bool env_prefetch_ok(const EnvDev &p) {
+    return SCEN == CM_PP && LPE < 64 && p.N <= LPE && p.M <= LPE && p.S <= LPE && (p.M + 1) + (p.N + 1) <= LPE;
+}
+
+template <int SCEN, int LPE>
+__device__ __forceinline__ EnvPre env_prefetch(const EnvDev &p, int b_raw, bool grp_live) {
+    const int sl = thread_x() % LPE;
+    const int b = (grp_live && b_raw < p.B) ? b_raw : p.B - 1;
+    const int S = p.S, N = p.N, M = p.M;
+    EnvPre e;
+    e.on = true;
+    e.step_count_in = p.step_count[b];
+    e.succ = p.success[b];
+    e.rng_step = p.rng_step[b];
+    const int s0 = sl < S ? sl : S - 1;
+    e.t_row = p.lut_row[s0]; e.t_col = p.lut_col[s0]; e.t_step0 = p.lut_step[0];
+    e.t_rew = p.rew_lut[sl < (M + 1) + (N + 1) ? sl : 0];
+    const int ia = sl < N ? sl : 0, ip = sl < M ? sl : 0;
+    { const int2 q = p.agent_pos[(size_t)b * N + ia]; e.ax = q.x; e.ay = q.y; }
+    e.cond = p.agent_cond[(size_t)b * N + ia];
+    { const int2 q = p.prey_pos[(size_t)b * M + ip]; e.px = q.x; e.py = q.y; }
+    e.alive = p.alive[(size_t)b * M + ip];
+    const int sc = e.step_count_in + 1;
+    e.t_step = p.lut_step[sc <= p.max_steps ? sc : p.max_steps];
+    return e;
+}
+
+// The prefetched agent / prey rows into the env's LDS arrays (what env_body's own load loops do), one lane each.
+// Returns the lane's bad-action flag.
+template <int SCEN, int LPE>
+__device__ __forceinline__ bool env_stage(const EnvDev &p, const EnvPre &e, const int32_t *act_lds, int grp, int lds_base) {
+    const int sl = thread_x() % LPE;
+    const Lds l = make_lds(p.S, p.N, p.M, lds_base + p.lds_env * grp, p.status);
+    bool bad = false;
+    if (sl < p.N) {
+        AR(l, sl) = (int16_t)e.ax; AC(l, sl) = (int16_t)e.ay;
+        const int a = act_lds[sl];
+        bad = (unsigned)a > 4u;
+        const bool faulty = SCEN == CM_PP && e.cond == 0;             // pseudo-action 5, as in env_body
+        ACT(l, sl) = (uint8_t)(bad ? 4 : ((faulty && a != 4) ? 5 : a));
+    }
+    if (SCEN == CM_PP && sl < p.M) { PR(l, sl) = (int16_t)e.px; PC(l, sl) = (int16_t)e.py; ALV(l, sl) = (uint8_t)e.alive; }
+    return bad;
+}
+
 template <int SCEN, int LPE>
 __device__ __forceinline__ void env_body(const EnvDev &p, const int32_t *__restrict__ actions, const int32_t *act_lds,
                                          const cm_rng_tape &tape, const cm_step_out &out, int reset_only, int grp, int b_raw,
-                                         bool grp_live, int lds_base, int *defer = nullptr) {
+                                         bool grp_live, int lds_base, int *defer = nullptr,
+                                         // PRE: state already staged in LDS by the caller (env_stage) and the scalars below prefetched
+                                         bool PRE = false, uint32_t pre_rng_step = 0, int pre_step_count_in = 0, int pre_succ = 0,
+                                         float pre_t_row = 0.0f, float pre_t_col = 0.0f, float pre_t_step0 = 0.0f,
+                                         float pre_t_step = 0.0f, double pre_t_rew = 0.0,
+                                         bool pre_bad = false) {
     Grp<LPE> g;
     const int tx = thread_x();
     g.sub = (tx & (WAVE - 1)) / LPE; g.sl = tx % LPE;
@@ -692,7 +756,7 @@ __device__ __forceinline__ void env_body(const EnvDev &p, const int32_t *__restr
     const int b = valid ? b_raw : p.B - 1;            // idle groups shadow the last env and never commit
     const Lds l = make_lds(p.S, p.N, p.M, lds_base + p.lds_env * grp, p.status);
     const int S = p.S, N = p.N, M = p.M;
-    Rng rng{ (uint32_t)(p.env_id_offset + b), p.rng_step[b], p.key0, p.key1 };
+    Rng rng{ (uint32_t)(p.env_id_offset + b), PRE ? pre_rng_step : p.rng_step[b], p.key0, p.key1 };
     cm_step_out o = out;
     if (!valid) { o.obs = nullptr; o.dist_adj = nullptr; o.channels = nullptr; }
 
@@ -705,17 +769,20 @@ __device__ __forceinline__ void env_body(const EnvDev &p, const int32_t *__restr
         return;
     }
 
-    const int step_count_in = p.step_count[b];         // requested first: the clock entry below depends on it
-    int succ = p.success[b];
+    const int step_count_in = PRE ? pre_step_count_in : p.step_count[b];   // requested first: the clock entry below depends on it
+    int succ = PRE ? pre_succ : p.success[b];
     // tables the end of the step needs, requested now (ObsTabs; the reward terms likewise: lane s holds rew_lut[s])
-    const bool tabs_held = S <= LPE;
-    const bool rew_held = SCEN == CM_PP && LPE < 64 && (M + 1) + (N + 1) <= LPE;
-    float t_row = 0.0f, t_col = 0.0f, t_step0 = 0.0f;
-    double t_rew = 0.0;
-    if (tabs_held) { const int s0 = sl < S ? sl : S - 1; t_row = p.lut_row[s0]; t_col = p.lut_col[s0]; t_step0 = p.lut_step[0]; }
-    if (rew_held) t_rew = p.rew_lut[sl < (M + 1) + (N + 1) ? sl : 0];
+    const bool tabs_held = PRE || S <= LPE;
+    const bool rew_held = PRE || (SCEN == CM_PP && LPE < 64 && (M + 1) + (N + 1) <= LPE);
+    float t_row = pre_t_row, t_col = pre_t_col, t_step0 = pre_t_step0;
+    double t_rew = pre_t_rew;
+    if (!PRE) {
+        if (tabs_held) { const int s0 = sl < S ? sl : S - 1; t_row = p.lut_row[s0]; t_col = p.lut_col[s0]; t_step0 = p.lut_step[0]; }
+        if (rew_held) t_rew = p.rew_lut[sl < (M + 1) + (N + 1) ? sl : 0];
+    }
     // ---- load SoA state, rebuild the occupancy tile in LDS ----
-    bool bad_action = false;
+    bool bad_action = pre_bad;
+    if (!PRE) {
     for (int i = sl; i < N; i += LPE) {
         const int2 q = p.agent_pos[(size_t)b * N + i];
         AR(l, i) = (int16_t)q.x; AC(l, i) = (int16_t)q.y;
@@ -734,6 +801,7 @@ __device__ __forceinline__ void env_body(const EnvDev &p, const int32_t *__restr
             PR(l, j) = (int16_t)q.x; PC(l, j) = (int16_t)q.y;
             ALV(l, j) = p.alive[(size_t)b * M + j];
         }
+    }
     for (int k = sl; k < S * S; k += LPE) Gc(l, k) = (SCEN == CM_CO) ? p.base_grid[k] : (uint8_t)C_EMPTY;
     if (SCEN == CM_CO) for (int r = sl; r < S; r += LPE) VIS(l, r) = p.visited[(size_t)b * S + r];
     // the reference raises on a bad action (predator_prey.py:255): flag it; the env is left untouched
@@ -755,8 +823,8 @@ __device__ __forceinline__ void env_body(const EnvDev &p, const int32_t *__restr
     ENV_PROBE(2);
     if (p.stop == 2) return;
     int step_count = step_count_in + 1;
-    float t_step = 0.0f;
-    if (tabs_held) t_step = p.lut_step[step_count <= p.max_steps ? step_count : p.max_steps];
+    float t_step = pre_t_step;
+    if (!PRE && tabs_held) t_step = p.lut_step[step_count <= p.max_steps ? step_count : p.max_steps];
     int done = 0;
     double reward;
     int det0 = 0, det1 = 0, det2 = 0, det3 = 0, det4 = 0, det5 = 0;

@@ -30,20 +30,31 @@ __device__ __forceinline__ void policy_body(const mf::FwdArgs &a, const mf::Trun
 
 // FULL: the constant-shape build for teams of 4 with every workgroup full (8 envs, S % 8 == 0) - team size, rows and
 // the LDS map are compile-time constants in the policy body (cm_policy_h_dev.h) and the env count here.
-template <int SCEN, int LPE, int KPAD, int MAXMK, int POL, bool FULL = false>
+template <int SCEN, int LPE, int KPAD, int MAXMK, int POL, bool FULL = false, bool PRE = false>
 __global__ __launch_bounds__(mf::TPB) void rollout_step_kernel(mf::FwdArgs a, mf::TrunkW tw, mf::PolHead ph, mh::TrunkH twh,
                                                                mh::PolHeadH phh, EnvDev p, cm_rng_tape tape, cm_step_out out,
                                                                int act_off) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     int32_t *act = reinterpret_cast<int32_t *>(lds + act_off);           // [EPB*N] sampled actions, behind the policy tiles
-    policy_body<POL, KPAD, MAXMK, FULL>(a, tw, ph, twh, phh, lds, act);
-    __syncthreads();                                                     // actions visible; the policy tiles are dead
     const int tx = thread_x(), grp = tx / LPE;
     const int EPBc = FULL ? 8 : a.EPB;
     const int envs = FULL ? 8 : min(a.EPB, a.S - (int)blockIdx.x * a.EPB);
-    if ((tx & ~63) / LPE >= envs) return;                               // a wave with no env of its own (the env body syncs wave-locally)
     const bool live = grp < envs;
-    env_body<SCEN, LPE>(p, nullptr, act + (live ? grp : 0) * p.N, tape, out, 0, grp, blockIdx.x * EPBc + (live ? grp : 0), live, 0);
+    const bool env_wave = (tx & ~63) / LPE < envs;                      // a wave with an env of its own (the env body syncs wave-locally)
+    const int b_raw = blockIdx.x * EPBc + (live ? grp : 0);
+    // PRE (host-checked: env_prefetch_ok): the env state does not depend on the actions - requested in front of the
+    // policy forward, consumed behind it
+    EnvPre pre{};
+    if constexpr (PRE) pre = env_prefetch<SCEN, LPE>(p, b_raw, live);
+    policy_body<POL, KPAD, MAXMK, FULL>(a, tw, ph, twh, phh, lds, act);
+    __syncthreads();                                                     // actions visible; the policy tiles are dead
+    if (!env_wave) return;
+    const int32_t *my_act = act + (live ? grp : 0) * p.N;
+    if constexpr (PRE) {
+        const bool bad = env_stage<SCEN, LPE>(p, pre, my_act, grp, 0);
+        env_body<SCEN, LPE>(p, nullptr, my_act, tape, out, 0, grp, b_raw, live, 0, nullptr, true, pre.rng_step, pre.step_count_in, pre.succ,
+                            pre.t_row, pre.t_col, pre.t_step0, pre.t_step, pre.t_rew, bad);
+    } else env_body<SCEN, LPE>(p, nullptr, my_act, tape, out, 0, grp, b_raw, live, 0);
 }
 
 // Persistent form: the workgroup keeps its envs for n_steps consecutive steps (policy -> env -> policy ...), pointers
@@ -131,6 +142,7 @@ static int launch_fused(mf::FwdArgs a, const mf::TrunkW &tw, const mf::PolHead &
         attr_set = true;
     }
     const int blocks = (a.S + a.EPB - 1) / a.EPB;
+    static const int pre_flag = [] { const char *e = getenv("COMMARL_ENV_PREFETCH"); return (e && e[0] == '0') ? 0 : 1; }();
     if (chunk) {
         static bool attr_set_c = false;
         if (!attr_set_c) {
@@ -146,16 +158,22 @@ static int launch_fused(mf::FwdArgs a, const mf::TrunkW &tw, const mf::PolHead &
     if constexpr (MAXMK < 0 && POL == 1) {
         static const bool full_on = [] { const char *e = getenv("COMMARL_FWD_FULL"); return !(e && e[0] == '0'); }();
         if (full_on && a.EPB == 8 && a.S % 8 == 0) {
-            static bool attr_set_f = false;
-            if (!attr_set_f) {
-                CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_step_kernel<SCEN, LPE, KPAD, MAXMK, POL, true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                attr_set_f = true;
-            }
-            hipLaunchKernelGGL((rollout_step_kernel<SCEN, LPE, KPAD, MAXMK, POL, true>), dim3(blocks), dim3(mf::TPB), lds,
-                               (hipStream_t)stream, a, tw, ph, twh, phh, d, t, out, (int)pol_floats);
-            CM_HIP(hipGetLastError());
-            return CM_OK;
+#define CM_FULL_LAUNCH(PRE)                                                                                                       \
+    do {                                                                                                                          \
+        static bool attr_set_f = false;                                                                                           \
+        if (!attr_set_f) {                                                                                                        \
+            CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_step_kernel<SCEN, LPE, KPAD, MAXMK, POL, true, PRE>), \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                                  \
+            attr_set_f = true;                                                                                                    \
+        }                                                                                                                         \
+        hipLaunchKernelGGL((rollout_step_kernel<SCEN, LPE, KPAD, MAXMK, POL, true, PRE>), dim3(blocks), dim3(mf::TPB), lds,       \
+                           (hipStream_t)stream, a, tw, ph, twh, phh, d, t, out, (int)pol_floats);                                 \
+        CM_HIP(hipGetLastError());                                                                                                \
+        return CM_OK;                                                                                                             \
+    } while (0)
+            if (pre_flag && env_prefetch_ok<SCEN, LPE>(d)) CM_FULL_LAUNCH(true);
+            CM_FULL_LAUNCH(false);
+#undef CM_FULL_LAUNCH
         }
     }
     hipLaunchKernelGGL((rollout_step_kernel<SCEN, LPE, KPAD, MAXMK, POL>), dim3(blocks), dim3(mf::TPB), lds, (hipStream_t)stream, a, tw,
