@@ -565,12 +565,32 @@ __device__ __forceinline__ SmallOut pp_small_step(const EnvDev &p, const Lds l, 
                                                   const Grp<LPE> g) {
     const int N = p.N, M = p.M, S = p.S, sl = g.sl;
     int ar[R], ac[R], act[R], pr[R], pc[R];
+    {
+        // every array starts on a 16-byte boundary of its own 16-byte-rounded slot (lds_take): the <= 8 int16 / u8 entries of
+        // one array are ONE wide read (entries past N / M are padding and masked below)
+        uint32_t w_ar[R / 2], w_ac[R / 2], w_pr[R / 2], w_pc[R / 2], w_act[R / 4], w_alv[R / 4];
+        if constexpr (R == 8) {
+            const uint4 a = *reinterpret_cast<const uint4 *>(smem + l.ar), c = *reinterpret_cast<const uint4 *>(smem + l.ac);
+            const uint4 q = *reinterpret_cast<const uint4 *>(smem + l.pr), d = *reinterpret_cast<const uint4 *>(smem + l.pc);
+            const uint2 t = *reinterpret_cast<const uint2 *>(smem + l.act), v = *reinterpret_cast<const uint2 *>(smem + l.alive);
+            w_ar[0] = a.x; w_ar[1] = a.y; w_ar[2] = a.z; w_ar[3] = a.w; w_ac[0] = c.x; w_ac[1] = c.y; w_ac[2] = c.z; w_ac[3] = c.w;
+            w_pr[0] = q.x; w_pr[1] = q.y; w_pr[2] = q.z; w_pr[3] = q.w; w_pc[0] = d.x; w_pc[1] = d.y; w_pc[2] = d.z; w_pc[3] = d.w;
+            w_act[0] = t.x; w_act[1] = t.y; w_alv[0] = v.x; w_alv[1] = v.y;
+        } else {
+            const uint2 a = *reinterpret_cast<const uint2 *>(smem + l.ar), c = *reinterpret_cast<const uint2 *>(smem + l.ac);
+            const uint2 q = *reinterpret_cast<const uint2 *>(smem + l.pr), d = *reinterpret_cast<const uint2 *>(smem + l.pc);
+            w_ar[0] = a.x; w_ar[1] = a.y; w_ac[0] = c.x; w_ac[1] = c.y; w_pr[0] = q.x; w_pr[1] = q.y; w_pc[0] = d.x; w_pc[1] = d.y;
+            w_act[0] = *reinterpret_cast<const uint32_t *>(smem + l.act); w_alv[0] = *reinterpret_cast<const uint32_t *>(smem + l.alive);
+        }
 #pragma unroll
-    for (int i = 0; i < R; ++i) {                      // unconditional reads (index clamped) so that all are in flight together
-        const int ia = i < N ? i : 0, ip = i < M ? i : 0;
-        const int r = AR(l, ia), c = AC(l, ia), a = ACT(l, ia), qr = PR(l, ip), qc = PC(l, ip), alive = ALV(l, ip);
-        ar[i] = i < N ? r + 1 : GONE; ac[i] = i < N ? c + 1 : GONE; act[i] = i < N ? a : 4;
-        pr[i] = ((i < M) & (alive != 0)) ? qr + 1 : GONE; pc[i] = ((i < M) & (alive != 0)) ? qc + 1 : GONE;
+        for (int i = 0; i < R; ++i) {
+            const int sh = (i & 1) * 16, sb = (i & 3) * 8;
+            const int r = (int)(int16_t)(w_ar[i / 2] >> sh), c = (int)(int16_t)(w_ac[i / 2] >> sh);
+            const int qr = (int)(int16_t)(w_pr[i / 2] >> sh), qc = (int)(int16_t)(w_pc[i / 2] >> sh);
+            const int a = (w_act[i / 4] >> sb) & 0xff, alive = (w_alv[i / 4] >> sb) & 0xff;
+            ar[i] = i < N ? r + 1 : GONE; ac[i] = i < N ? c + 1 : GONE; act[i] = i < N ? a : 4;
+            pr[i] = ((i < M) & (alive != 0)) ? qr + 1 : GONE; pc[i] = ((i < M) & (alive != 0)) ? qc + 1 : GONE;
+        }
     }
     const bool mine = sl < M;                          // this lane's prey for the trials: start-of-step values
     int my_r, my_c;
@@ -632,11 +652,19 @@ __device__ __forceinline__ SmallOut pp_small_step(const EnvDev &p, const Lds l, 
     o.wsum = g.count(next_to<R>(pr, pc, my_ar, my_ac) != 0);                 // absent agents sit next to nothing
     ENV_SYNC();
     int pcnt[R], pmv[R];
+    {
+        uint32_t w_cnt[R / 4], w_mv[R / 4];
+        if constexpr (R == 8) {
+            const uint2 a = *reinterpret_cast<const uint2 *>(smem + l.pcnt), c = *reinterpret_cast<const uint2 *>(smem + l.pmv);
+            w_cnt[0] = a.x; w_cnt[1] = a.y; w_mv[0] = c.x; w_mv[1] = c.y;
+        } else {
+            w_cnt[0] = *reinterpret_cast<const uint32_t *>(smem + l.pcnt); w_mv[0] = *reinterpret_cast<const uint32_t *>(smem + l.pmv);
+        }
 #pragma unroll
-    for (int j = 0; j < R; ++j) {
-        const int jp = j < M ? j : 0;
-        const int cn = PCNT(l, jp), mb = PMV(l, jp);
-        pcnt[j] = j < M ? cn : 0; pmv[j] = j < M ? mb : 4;
+        for (int j = 0; j < R; ++j) {
+            const int sb = (j & 3) * 8;
+            pcnt[j] = j < M ? (int)((w_cnt[j / 4] >> sb) & 0xff) : 0; pmv[j] = j < M ? (int)((w_mv[j / 4] >> sb) & 0xff) : 4;
+        }
     }
     ENV_SYNC();
     ENV_PROBE(4);

@@ -120,6 +120,17 @@ __global__ __launch_bounds__(mf::TPB, 2) void rollout_chunk_kernel(mf::FwdArgs a
     }
 }
 
+// diagnostic (COMMARL_ENV_STOP=-1): phase clocks of workgroup 0's env phase inside the fused step (ENV_PROBE, cm_env_dev.h)
+static void probe_dump(const EnvDev &d, void *stream) {
+    if (d.stop >= 0) return;
+    unsigned long long h_probe[16];
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return;
+    if (hipMemcpyFromSymbol(h_probe, HIP_SYMBOL(g_env_probe), sizeof(h_probe)) != hipSuccess) return;
+    fprintf(stderr, "[fused env probe] clk since env entry:");
+    for (int i = 1; i < 10; ++i) fprintf(stderr, " p%d=%lld", i, (long long)(h_probe[i] - h_probe[0]));
+    fprintf(stderr, "\n");
+}
+
 template <int SCEN, int LPE, int KPAD, int MAXMK, int POL>
 static int launch_fused(mf::FwdArgs a, const mf::TrunkW &tw, const mf::PolHead &ph, const mh::TrunkH &twh, const mh::PolHeadH &phh,
                         const cm_env *h, const cm_rng_tape &t, const cm_step_out &out, void *stream, const ChunkArgs *chunk = nullptr) {
@@ -169,6 +180,7 @@ static int launch_fused(mf::FwdArgs a, const mf::TrunkW &tw, const mf::PolHead &
         hipLaunchKernelGGL((rollout_step_kernel<SCEN, LPE, KPAD, MAXMK, POL, true, PRE>), dim3(blocks), dim3(mf::TPB), lds,       \
                            (hipStream_t)stream, a, tw, ph, twh, phh, d, t, out, (int)pol_floats);                                 \
         CM_HIP(hipGetLastError());                                                                                                \
+        probe_dump(d, stream);                                                                                                    \
         return CM_OK;                                                                                                             \
     } while (0)
             if (pre_flag && env_prefetch_ok<SCEN, LPE>(d)) CM_FULL_LAUNCH(true);
