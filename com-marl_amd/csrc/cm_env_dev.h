@@ -22,8 +22,11 @@ constexpr int PAR_AGENTS_MIN = 16;  // teams larger than this resolve their move
 static __device__ unsigned long long g_env_probe[16];
 #define ENV_PROBE(i) do { asm volatile("; ENV_PROBE " #i); if (p.stop < 0 && blockIdx.x == 0 && thread_x() == 0) g_env_probe[i] = __builtin_amdgcn_s_memtime(); } while (0)
 
-__device__ __forceinline__ int dr_of(int a) { return a == 0 ? 1 : (a == 2 ? -1 : 0); }   // predator_prey.py:244-253
-__device__ __forceinline__ int dc_of(int a) { return a == 1 ? -1 : (a == 3 ? 1 : 0); }
+// displacement of action a (predator_prey.py:244-253; 0 down, 1 left, 2 up, 3 right, 4 stay, 5 = the faulty agent's
+// "no displacement"): delta + 1 as six 2-bit fields of a constant - shift, field extract, add instead of two compare / select
+// pairs (these sit in every iteration of the order-dependent loops)
+__device__ __forceinline__ int dr_of(int a) { return (int)((1350u >> (2 * a)) & 3u) - 1; }   // +1 0 -1 0 0 0
+__device__ __forceinline__ int dc_of(int a) { return (int)((1425u >> (2 * a)) & 3u) - 1; }   // 0 -1 0 +1 0 0
 __device__ __forceinline__ bool in_grid(int r, int c, int S) { return (unsigned)r < (unsigned)S && (unsigned)c < (unsigned)S; }
 // (cell / count_adj are defined after the LDS accessors)
 // _neighbour_agents / _neighbour_preys count (predator_prey.py:309-351): D,U,R,L, each bounds-checked
