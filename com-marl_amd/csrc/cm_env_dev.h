@@ -714,7 +714,6 @@ __device__ __forceinline__ SmallOut pp_small_step(const EnvDev &p, const Lds l, 
 // step (the fused rollout kernel: the whole policy forward) requests it first and hands it over in registers, so the
 // env phase starts without a memory round trip.  One lane = one agent and one prey (teams <= lanes per env).
 struct EnvPre {
-    bool on;
     uint32_t rng_step;
     int step_count_in, succ;
     float t_row, t_col, t_step0, t_step;
@@ -734,7 +733,6 @@ __device__ __forceinline__ EnvPre env_prefetch(const EnvDev &p, int b_raw, bool 
     const int b = (grp_live && b_raw < p.B) ? b_raw : p.B - 1;
     const int S = p.S, N = p.N, M = p.M;
     EnvPre e;
-    e.on = true;
     e.step_count_in = p.step_count[b];
     e.succ = p.success[b];
     e.rng_step = p.rng_step[b];
