@@ -9,6 +9,9 @@ pytestmark = pytest.mark.gpu
 SHAPES = {
     # name: (scenario, map, sen, N, M, load, loss, B, steps, mpl)
     "pp_map10": ("pp", 10, 1, 4, 4, 2, 0.0, 203, 40, 9),
+    # every workgroup full (a multiple of 8 envs): the constant-shape build with the env state prefetched in front of
+    # the policy forward (rollout_step_kernel<..., FULL, PRE>, cm_fused.hip)
+    "pp_map10_full": ("pp", 10, 1, 4, 4, 2, 0.0, 208, 40, 9),
     "co_map20": ("co", 20, 2, 24, 0, 2, 0.0, 7, 14, 6),
     "pp_map30": ("pp", 30, 2, 72, 72, 4, 0.0, 3, 8, 5),
     "co_map30_iid": ("co", 30, 2, 54, 0, 2, 0.3, 3, 8, 5),
@@ -22,12 +25,15 @@ def _params(scen, map_, sen, N, M, load, loss, mpl):
                 n_preys=M, n_gcn_layers=2, mode="train", trRcom=9, trpl=loss, obstComplex="Easy", add_clock=0)
 
 
-def _run(torch, shape, fused, greedy, chunked=False):
+def _run(torch, shape, fused, greedy, chunked=False, faults=False):
     from com_marl_amd import envs as E, nets
     from com_marl_amd.rollout import RolloutEngine
     scen, map_, sen, N, M, load, loss, B, steps, mpl = SHAPES[shape]
     env = E.GridEnvBatch(scen, _params(scen, map_, sen, N, M, load, loss, mpl), B, device="cuda:0", seed=3,
                          max_steps=mpl if scen == "pp" else 400, max_path_length=mpl, env_id_offset=11)
+    if faults:           # some agents cannot move (predator_prey.py:257-261): their condition travels with the prefetch
+        env.apply_agent_fault("iid", 0.35, fault_step=2)
+        assert 0 < env.agent_condition.mean() < 1
     spec = E.EnvSpec(E._Box(np.zeros(env.d * N), np.ones(env.d * N)), E._Discrete(5))
     torch.manual_seed(3)
     pol = nets.CommCategoricalMLPPolicy(spec, n_agents=N, device="cuda:0")
@@ -59,6 +65,22 @@ def test_fused_step_is_bit_identical_to_two_launches(shape, greedy):
     b, used_b = _run(torch, shape, False, greedy)
     assert used_b is False
     assert a["done"].any(), "the window should contain auto-resets"
+    for k in sorted(b):
+        if k == "state":
+            for kk in b[k]:
+                np.testing.assert_array_equal(a[k][kk], b[k][kk], err_msg=f"state.{kk}")
+        else:
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+
+
+@pytest.mark.parametrize("shape", ["pp_map10", "pp_map10_full"])
+def test_fused_step_with_agent_faults(shape):
+    """Faulty agents (condition 0: the move is computed, counted and not applied) through the fused step's own staging of
+    the env state - ragged and full workgroups - against the two-launch path."""
+    import torch
+    a, used = _run(torch, shape, True, False, faults=True)
+    assert used is True
+    b, _ = _run(torch, shape, False, False, faults=True)
     for k in sorted(b):
         if k == "state":
             for kk in b[k]:
