@@ -775,13 +775,14 @@ __device__ __forceinline__ void env_body(const EnvDev &p, const int32_t *__restr
                                          bool PRE = false, uint32_t pre_rng_step = 0, int pre_step_count_in = 0, int pre_succ = 0,
                                          float pre_t_row = 0.0f, float pre_t_col = 0.0f, float pre_t_step0 = 0.0f,
                                          float pre_t_step = 0.0f, double pre_t_rew = 0.0,
-                                         bool pre_bad = false) {
+                                         bool pre_bad = false,
+                                         bool all_valid = false /* the caller vouches: every group has an env of its own below p.B */) {
     Grp<LPE> g;
     const int tx = thread_x();
     g.sub = (tx & (WAVE - 1)) / LPE; g.sl = tx % LPE;
     const int sl = g.sl;
     ENV_PROBE(0);
-    const bool valid = grp_live && b_raw < p.B;
+    const bool valid = all_valid || (grp_live && b_raw < p.B);
     const int b = valid ? b_raw : p.B - 1;            // idle groups shadow the last env and never commit
     const Lds l = make_lds(p.S, p.N, p.M, lds_base + p.lds_env * grp, p.status);
     const int S = p.S, N = p.N, M = p.M;

@@ -39,8 +39,9 @@ __global__ __launch_bounds__(mf::TPB) void rollout_step_kernel(mf::FwdArgs a, mf
     const int tx = thread_x(), grp = tx / LPE;
     const int EPBc = FULL ? 8 : a.EPB;
     const int envs = FULL ? 8 : min(a.EPB, a.S - (int)blockIdx.x * a.EPB);
-    const bool live = grp < envs;
-    const bool env_wave = (tx & ~63) / LPE < envs;                      // a wave with an env of its own (the env body syncs wave-locally)
+    constexpr bool ALL = FULL && LPE == 32;                              // 8 envs x 32 lanes: every group of every wave has its env
+    const bool live = ALL || grp < envs;
+    const bool env_wave = ALL || (tx & ~63) / LPE < envs;               // a wave with an env of its own (the env body syncs wave-locally)
     const int b_raw = blockIdx.x * EPBc + (live ? grp : 0);
     // PRE (host-checked: env_prefetch_ok): the env state does not depend on the actions - requested in front of the
     // policy forward, consumed behind it
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(mf::TPB) void rollout_step_kernel(mf::FwdArgs a, mf
     if constexpr (PRE) {
         const bool bad = env_stage<SCEN, LPE>(p, pre, my_act, grp, 0);
         env_body<SCEN, LPE>(p, nullptr, my_act, tape, out, 0, grp, b_raw, live, 0, nullptr, true, pre.rng_step, pre.step_count_in, pre.succ,
-                            pre.t_row, pre.t_col, pre.t_step0, pre.t_step, pre.t_rew, bad);
+                            pre.t_row, pre.t_col, pre.t_step0, pre.t_step, pre.t_rew, bad, ALL);
     } else env_body<SCEN, LPE>(p, nullptr, my_act, tape, out, 0, grp, b_raw, live, 0);
 }
 
