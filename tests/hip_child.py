@@ -19,6 +19,7 @@ CASES = {
     "env_lpe64_small_team": (dict(COMMARL_ENV_LPE="64"), "one wave per env forced for teams of 4 / 6: wide and narrow"),
     "env_lpe16_mid_team": (dict(COMMARL_ENV_LPE="16"), "16 lanes per env forced for teams of 12 / 16"),
     "env_wide_off": (dict(COMMARL_ENV_WIDE="0"), "narrow one-wave-per-env kernels for large teams at small batches"),
+    "env_small_off": (dict(COMMARL_ENV_SMALL="0"), "occupancy-tile walk kept for small PP teams (the A/B of pp_small_step)"),
     "debug_library_env_goldens": (dict(COMMARL_LIB=os.path.join(ROOT, "com-marl_amd", "libcommarl_hip_dbg.so")),
                                   "range-checked (-DCM_BOUNDS) build: env goldens + Philox lock-step"),
     "two_rank_train_once": ({}, "CentralizedMAPPO.train_once on 2 gloo ranks (both on GPU 0) == 1 process on the union (2 clipped steps; 5 steps without the ratio clip)"),
@@ -36,6 +37,14 @@ def env_lpe32():
     n += _lock(dict(scenario="pp", n_envs=203, n_agents=4, n_preys=4, grid=10, rsen=1, load=2, max_steps=9), 22)
     n += _lock(dict(scenario="pp", n_envs=130, n_agents=20, n_preys=17, grid=16, rsen=2, load=3, max_steps=9, rcom=4,
                     channel="IID", ploss=0.2), 22)
+    # register-resident loops, 8-entity build (pp_small_step<32, 8>), capture rule of load 3 (neighbouring preys count)
+    n += _lock(dict(scenario="pp", n_envs=150, n_agents=7, n_preys=8, grid=11, rsen=1, load=3, max_steps=9, rcom=3), 22)
+    return dict(dones=n)
+
+
+def env_small_off():
+    n = _lock(dict(scenario="pp", n_envs=203, n_agents=4, n_preys=4, grid=10, rsen=1, load=2, max_steps=9), 22)
+    n += _lock(dict(scenario="pp", n_envs=100, n_agents=5, n_preys=7, grid=12, rsen=2, load=3, max_steps=9, rcom=3), 22)
     return dict(dones=n)
 
 

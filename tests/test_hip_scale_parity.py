@@ -181,7 +181,7 @@ def test_env_32_lanes_per_env_from_8192_envs(torch_cuda):
 
 
 # ---- branches and builds selected by environment knobs: run in fresh child processes (tests/conftest.py) --------------
-@pytest.mark.parametrize("case", ["env_lpe32", "env_lpe64_small_team", "env_lpe16_mid_team", "env_wide_off",
+@pytest.mark.parametrize("case", ["env_lpe32", "env_lpe64_small_team", "env_lpe16_mid_team", "env_wide_off", "env_small_off",
                                   "debug_library_env_goldens"])
 def test_env_knob_branches_in_child_processes(case):
     """COMMARL_ENV_LPE / COMMARL_ENV_WIDE are read once per process and COMMARL_LIB selects the CM_BOUNDS debug build, so
