@@ -520,7 +520,7 @@ __device__ __forceinline__ MoveOut agents_parallel(const EnvDev &p, const Lds l,
 // In: AR / AC / ACT / PR / PC / ALV staged in LDS, tile all C_EMPTY.  Out: the same arrays and the tile at their
 // end-of-step values, as the tile walk leaves them.  Reference lines as in env_body below.
 // ---------------------------------------------------------------------------------------
-struct SmallOut { int moving, capture, penalty, wsum, my_alive; bool tape_short, any_alive; };   // my_alive: lane s = prey s
+struct SmallOut { int moving, capture, penalty, wsum; bool tape_short, any_alive; };
 
 // Straight-line code throughout (selects, no short-circuit operators: hipcc turns every `&&` on lane data into an
 // exec-mask branch), and no long-lived booleans (each one is a 64-bit lane mask in scalar registers: an `alive[R]` array
@@ -608,7 +608,7 @@ __device__ __forceinline__ SmallOut pp_small_step(const EnvDev &p, const Lds l, 
     if (mine && !taped) x0 = rng.at(SITE_PREY, (uint32_t)(2 * sl));
     ENV_SYNC();
 
-    SmallOut o{ 0, 0, 0, 0, 0, false, false };
+    SmallOut o{ 0, 0, 0, 0, false, false };
     // ---- agents move in index order (predator_prey.py:497-500, :240-261) ----
 #pragma unroll
     for (int i = 0; i < R; ++i) {
@@ -701,7 +701,6 @@ __device__ __forceinline__ SmallOut pp_small_step(const EnvDev &p, const Lds l, 
 #pragma unroll
     for (int j = 0; j < R; ++j) { my_pr = sl == j ? pr[j] : my_pr; my_pc = sl == j ? pc[j] : my_pc; }
     if (sl < N) { AR(l, sl) = (int16_t)(my_ar - 1); AC(l, sl) = (int16_t)(my_ac - 1); Gc(l, (my_ar - 1) * S + my_ac - 1) = C_AGENT; }
-    o.my_alive = my_pr != GONE;
     if (mine) {
         const bool my_al = my_pr != GONE;
         ALV(l, sl) = (uint8_t)my_al;
@@ -865,11 +864,10 @@ __device__ __forceinline__ void env_body(const EnvDev &p, const int32_t *__restr
         int moving = 0;
         int capture = 0, penalty = 0, wsum = 0;
         bool tape_short = false, any_alive = false;
-        int small_alive = 0;
         if (LPE < 64 && small) {
             const SmallOut so = (N <= 4 && M <= 4) ? pp_small_step<LPE, 4>(p, l, rng, tape, b, g) : pp_small_step<LPE, 8>(p, l, rng, tape, b, g);
             moving = so.moving; capture = so.capture; penalty = so.penalty; wsum = so.wsum; tape_short = so.tape_short;
-            any_alive = so.any_alive; small_alive = so.my_alive;
+            any_alive = so.any_alive;
             ENV_PROBE(5);
         } else {
         if (N > PAR_AGENTS_MIN) moving = agents_parallel<SCEN, LPE>(p, l, g).moving;      // large teams: parallel resolution
@@ -1044,10 +1042,7 @@ __device__ __forceinline__ void env_body(const EnvDev &p, const int32_t *__restr
         else reward = p.rew_lut[capture] + p.rew_lut[(M + 1) + moving];
         if (p.load == 2) reward = reward + p.penalty * (double)penalty;
         det0 = capture; det1 = moving; det2 = penalty; det4 = wsum;
-        if (o.prey_alive && commit) {
-            if (LPE < 64 && small) { if (sl < M) o.prey_alive[(size_t)b * M + sl] = (uint8_t)small_alive; }   // still in the lane's register
-            else for (int j = sl; j < M; j += LPE) o.prey_alive[(size_t)b * M + j] = ALV(l, j);
-        }
+        if (o.prey_alive && commit) for (int j = sl; j < M; j += LPE) o.prey_alive[(size_t)b * M + j] = ALV(l, j);
         done = (step_count >= p.max_steps) || !any_alive;               // :511-517
         if (done) succ = any_alive ? 0 : 1;
     } else {
