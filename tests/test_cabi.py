@@ -122,3 +122,32 @@ def test_env_kernels_use_no_flat_or_scratch_addressing(tmp_path):
     assert len(re.findall(r"^\s+ds_", asm, re.M)) > 1000
     for m in re.finditer(r"\.private_segment_fixed_size:\s+(\d+)", asm):
         assert m.group(1) == "0"
+
+
+def test_fused_step_kernels_use_no_flat_or_scratch_addressing(tmp_path):
+    """The same guard for the fused rollout step (cm_fused.hip: the env body runs inside the policy's workgroup): every
+    rollout_step_kernel instantiation - the kernels of the default rollout path - must request no private segment and
+    contain no flat / scratch instruction.  (The opt-in persistent chunk kernels are not covered: the all-f32 large-team
+    form spills two registers.)"""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "com-marl_amd", "csrc", "cm_fused.hip")
+    out = tmp_path / "cm_fused.s"
+    subprocess.check_call([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-mllvm",
+                           "-amdgpu-mfma-vgpr-form", "-S", "--cuda-device-only", "-w", "-o", str(out), src])
+    asm = out.read_text()
+    seen = 0
+    for blk in re.split(r"\n\s+- \.agpr_count:", asm)[1:]:                 # one metadata block per kernel
+        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+        if "rollout_step_kernel" not in name:
+            continue
+        seen += 1
+        assert re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1) == "0", name
+        assert re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1) == "0", name
+    assert seen >= 10, seen                                               # five shapes x two policy bodies (+ the full-workgroup builds)
+    for m in re.finditer(r"^(_ZN2cm19rollout_step_kernel\S+):\n(.*?)\n\.Lfunc_end", asm, re.M | re.S):
+        assert not re.search(r"^\s+(flat_(load|store|atomic)|scratch_)", m.group(2), re.M), m.group(1)
