@@ -189,3 +189,42 @@ def ptr(t):
 def current_stream():
     import torch
     return torch.cuda.current_stream().cuda_stream
+
+
+# ---- hipGraph captures must not contain a hipFree: env handles released while a capture is open (a garbage-collected
+# GridEnvBatch -> cm_env_destroy -> hipFree invalidated a capture in round 2) are parked here and destroyed afterwards ----
+_capture_depth = 0
+_deferred_env_handles = []
+
+
+def destroy_env(handle):
+    """cm_env_destroy now, or after the innermost open capture_guard() has closed."""
+    if _capture_depth > 0:
+        _deferred_env_handles.append(handle)
+        return
+    lib().cm_env_destroy(handle)
+
+
+class capture_guard:
+    """``with capture_guard(): <stream capture>``: collects garbage BEFORE the capture opens, keeps the cyclic collector off
+    while it is open, and defers every env-handle destruction requested meanwhile to the exit."""
+
+    def __enter__(self):
+        global _capture_depth
+        import gc
+        gc.collect()
+        self._gc_was_on = gc.isenabled()
+        gc.disable()
+        _capture_depth += 1
+        return self
+
+    def __exit__(self, *exc):
+        global _capture_depth
+        import gc
+        _capture_depth -= 1
+        if self._gc_was_on:
+            gc.enable()
+        if _capture_depth == 0:
+            while _deferred_env_handles:
+                lib().cm_env_destroy(_deferred_env_handles.pop())
+        return False

@@ -103,6 +103,13 @@ class CentralizedMAPPO:
         self.episode_reward_mean = collections.deque(maxlen=100)
         self.stats = {}
 
+    def __getstate__(self):
+        """Snapshots pickle the algo (snapshotter.py:102-104); a HIP stream is not picklable and is re-made on first use."""
+        st = dict(self.__dict__)
+        st.pop("_side_stream", None)
+        st.pop("_bucket", None)
+        return st
+
     @staticmethod
     def _check_entropy_configuration(entropy_method, center_adv, stop_entropy_gradient, policy_ent_coeff):
         if entropy_method not in ('max', 'regularized', 'no_entropy'):
@@ -328,9 +335,14 @@ class CentralizedMAPPO:
     # gradient exchange
     # ------------------------------------------------------------------------------------------
     def _allreduce_grads(self, n_valid, n_crit):
-        """One RCCL all-reduce of [policy grads ‖ critic grads ‖ n_valid ‖ n_crit] (dist.allreduce_sum_grads)."""
-        from .dist import allreduce_sum_grads
-        allreduce_sum_grads(list(self.policy.parameters()), list(self.baseline.parameters()), n_valid, n_crit)
+        """One RCCL all-reduce of [policy grads ‖ critic grads ‖ n_valid ‖ n_crit] through the persistent bucket
+        (dist.GradBucket): nothing is allocated and nothing waits for the host per optimiser step."""
+        from .dist import GradBucket
+        pol, cri = list(self.policy.parameters()), list(self.baseline.parameters())
+        b = getattr(self, "_bucket", None)
+        if b is None or not b.matches(pol, cri) or b.flat.device != pol[0].device:
+            b = self._bucket = GradBucket(pol, cri)
+        b.allreduce(n_valid, n_crit)
 
     # ------------------------------------------------------------------------------------------
     # train_once (:175-388)

@@ -147,20 +147,18 @@ static int launch_fused(mf::FwdArgs a, const mf::TrunkW &tw, const mf::PolHead &
     if (env_bytes > pol_floats * sizeof(float)) return 1;                // env area would reach into the action array
     const size_t lds = (pol_floats + (size_t)a.EPB * a.N) * sizeof(float);
     if (lds > 160 * 1024) return 1;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_set = 0;
+    if (cm::dev_first(attr_set)) {
         CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_step_kernel<SCEN, LPE, KPAD, MAXMK, POL>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
     }
     const int blocks = (a.S + a.EPB - 1) / a.EPB;
     static const int pre_flag = [] { const char *e = getenv("COMMARL_ENV_PREFETCH"); return (e && e[0] == '0') ? 0 : 1; }();
     if (chunk) {
-        static bool attr_set_c = false;
-        if (!attr_set_c) {
+        static unsigned long long attr_set_c = 0;
+        if (cm::dev_first(attr_set_c)) {
             CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_chunk_kernel<SCEN, LPE, KPAD, MAXMK, POL>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set_c = true;
         }
         hipLaunchKernelGGL((rollout_chunk_kernel<SCEN, LPE, KPAD, MAXMK, POL>), dim3(blocks), dim3(mf::TPB), lds, (hipStream_t)stream, a,
                            tw, ph, twh, phh, d, out, *chunk, (int)pol_floats);
@@ -172,11 +170,10 @@ static int launch_fused(mf::FwdArgs a, const mf::TrunkW &tw, const mf::PolHead &
         if (full_on && a.EPB == 8 && a.S % 8 == 0) {
 #define CM_FULL_LAUNCH(PRE)                                                                                                       \
     do {                                                                                                                          \
-        static bool attr_set_f = false;                                                                                           \
-        if (!attr_set_f) {                                                                                                        \
+        static unsigned long long attr_set_f = 0;                                                                                           \
+        if (cm::dev_first(attr_set_f)) {                                                                                                        \
             CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_step_kernel<SCEN, LPE, KPAD, MAXMK, POL, true, PRE>), \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                                  \
-            attr_set_f = true;                                                                                                    \
         }                                                                                                                         \
         hipLaunchKernelGGL((rollout_step_kernel<SCEN, LPE, KPAD, MAXMK, POL, true, PRE>), dim3(blocks), dim3(mf::TPB), lds,       \
                            (hipStream_t)stream, a, tw, ph, twh, phh, d, t, out, (int)pol_floats);                                 \

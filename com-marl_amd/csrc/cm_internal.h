@@ -18,6 +18,30 @@ int hip_fail(hipError_t e, const char *what);      // -> CM_ERR_HIP
         if (_e != hipSuccess) return ::cm::hip_fail(_e, #call); \
     } while (0)
 
+// Function attributes (hipFuncAttributeMaxDynamicSharedMemorySize) and CU counts belong to a DEVICE, not to the process:
+// a launcher's `static unsigned long long done` carries one bit per device ordinal, so a process that moves on to a second
+// GPU sets the attribute there too.  (Host launch paths are single-threaded per handle, include/commarl.h.)
+inline bool dev_first(unsigned long long &done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done & bit) return false;
+    done |= bit;
+    return true;
+}
+inline int cu_count() {
+    static int cached[64] = { 0 };
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    int &n = cached[dev & 63];
+    if (n <= 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        n = v;
+    }
+    return n;
+}
+
 // threadIdx.x through an opaque register: inside the step loop of the persistent rollout kernel the compiler otherwise
 // hoists every lane-derived address computation of both bodies out of the loop (several hundred live VGPRs: one
 // workgroup per CU, or 256 spilled registers when held to two).  Costs one move in the single-step kernels.

@@ -317,13 +317,12 @@ extern "C" int cm_linear_act_backward(int64_t R, int32_t K, int32_t O, const flo
     const int blocks = (int)std::min<long>(chunks, 512);
     const hipStream_t st = (hipStream_t)stream;
     const int per_wave = (NT + 3) / 4;
-    static bool once = false;
-    if (!once) {
+    static unsigned long long once = 0;
+    if (cm::dev_first(once)) {
 #define CM_ATTR(M, A) CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lin::bwd_kernel<M, A>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
         CM_ATTR(16, 0); CM_ATTR(8, 0); CM_ATTR(4, 0); CM_ATTR(2, 0); CM_ATTR(1, 0);
         CM_ATTR(16, 1); CM_ATTR(8, 1); CM_ATTR(4, 1); CM_ATTR(2, 1); CM_ATTR(1, 1);
 #undef CM_ATTR
-        once = true;
     }
 #define CM_LB(M) do { if (y) hipLaunchKernelGGL((lin::bwd_kernel<M, 1>), dim3(blocks), dim3(lin::TPB), lds, st, (long)R, K, O, x, w, w_layout, dy, dy2, y, dx, dw, db); \
                       else hipLaunchKernelGGL((lin::bwd_kernel<M, 0>), dim3(blocks), dim3(lin::TPB), lds, st, (long)R, K, O, x, w, w_layout, dy, dy2, y, dx, dw, db); } while (0)

@@ -463,13 +463,12 @@ static int launch(long R, int KR, const float *x, const float *w, const float *d
     constexpr int K = 16 * KT, O = 16 * OT;
     const size_t lds = ((size_t)2 * ROWS * (K + O + WO) + (ACT ? (size_t)ROWS * O : 0) + (dy2 ? (size_t)ROWS * O : 0)) * sizeof(float);
     if (lds > 160 * 1024) return 1;
-    static bool attr = false;
-    if (!attr) {
+    static unsigned long long attr = 0;
+    if (cm::dev_first(attr)) {
         CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bwd_kernel<KT, OT, ACT, LAYOUT, RAG, WO>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
     }
-    static const int n_cu = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+    const int n_cu = cm::cu_count();
     const long chunks = (R + ROWS - 1) / ROWS;
     const int blocks = (int)std::min<long>(chunks, n_cu);
     hipLaunchKernelGGL((bwd_kernel<KT, OT, ACT, LAYOUT, RAG, WO>), dim3(blocks), dim3(TPB), std::max<size_t>(lds, 33 * 1024), st, R, KR, x, w, dy, dy2, y, dx, dw,

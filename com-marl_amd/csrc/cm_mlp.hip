@@ -220,11 +220,10 @@ static int launch(Args a, void *stream) {
     a.sw = maxw + 4;                                         // +4 words: rows skewed across LDS banks, 16-byte aligned
     const size_t lds = 2ull * ROWS * a.sw * sizeof(float);
     if (lds > 160 * 1024) return set_error(CM_ERR_ARG, "mlp forward: layer too wide for the 160 KB LDS tile");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_set = 0;
+    if (cm::dev_first(attr_set)) {
         CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    160 * 1024));
-        attr_set = true;
     }
     if (a.rows == 0) return CM_OK;
     const int blocks = (a.rows + ROWS - 1) / ROWS;

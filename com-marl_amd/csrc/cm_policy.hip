@@ -256,10 +256,9 @@ static int launch_fwd(FwdArgs a, const TrunkW &tw, const PolHead &ph, const Crit
     a.EPB = pick_epb(a.N);
     const size_t lds = fwd_lds_floats(a.EPB * a.N, a.EPB, a.N) * sizeof(float);
     if (lds > 160 * 1024) return set_error(CM_ERR_ARG, "policy forward: n_agents too large for the 160 KB LDS tile");
-    static bool attr_set[2] = { false, false };
-    if (!attr_set[HEAD]) {
+    static unsigned long long attr_set[2] = { 0, 0 };
+    if (cm::dev_first(attr_set[HEAD])) {
         CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fwd_kernel<HEAD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set[HEAD] = true;
     }
     const int blocks = (a.S + a.EPB - 1) / a.EPB;
     hipLaunchKernelGGL(fwd_kernel<HEAD>, dim3(blocks), dim3(TPB), lds, (hipStream_t)stream, a, tw, ph, chd);

@@ -42,20 +42,18 @@ static int launch_h(FwdArgs a, const TrunkH &tw, const PolHeadH &ph, const CritH
     const int rows_cap = (a.EPB * a.N + 15) & ~15;
     const size_t lds = lds_map(rows_cap, a.EPB, a.N, MAXMK < 0 ? -1 : (MAXMK > 0 ? 1 : 0)).total;
     if (lds > 160 * 1024) return 1;                      // caller falls back (and reports the size limit there)
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_set = 0;
+    if (cm::dev_first(attr_set)) {
         CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fwd_h_kernel<HEAD, KH, MAXMK, NW>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
     }
     const int blocks = (a.S + a.EPB - 1) / a.EPB;
     if constexpr (MAXMK < 0 && NW == 4) {
         static const int occ_min = [] { const char *e = getenv("COMMARL_FWD_OCC3_MIN"); return e ? atoi(e) : 4096; }();   // workgroups; 0 = never
         if (occ_min > 0 && blocks >= occ_min) {
-            static bool attr3 = false;
-            if (!attr3) {
+            static unsigned long long attr3 = 0;
+            if (cm::dev_first(attr3)) {
                 CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fwd_h_occ3_kernel<HEAD, KH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                attr3 = true;
             }
             hipLaunchKernelGGL((fwd_h_occ3_kernel<HEAD, KH>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, a, tw, ph, chd);
             CM_HIP(hipGetLastError());
@@ -63,10 +61,9 @@ static int launch_h(FwdArgs a, const TrunkH &tw, const PolHeadH &ph, const CritH
         }
         static const bool full_on = [] { const char *e = getenv("COMMARL_FWD_FULL"); return !(e && e[0] == '0'); }();
         if (full_on && a.EPB == 8 && a.S % 8 == 0) {
-            static bool attrf = false;
-            if (!attrf) {
+            static unsigned long long attrf = 0;
+            if (cm::dev_first(attrf)) {
                 CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fwd_h_full_kernel<HEAD, KH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                attrf = true;
             }
             hipLaunchKernelGGL((fwd_h_full_kernel<HEAD, KH>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, a, tw, ph, chd);
             CM_HIP(hipGetLastError());

@@ -42,11 +42,10 @@ static int launch(FwdArgs a, const TrunkW &tw, const PolHead &ph, const CritHead
     const int rows_cap = (a.EPB * a.N + 15) & ~15;
     const size_t lds = lds_floats(rows_cap, a.EPB, a.N) * sizeof(float);
     if (lds > 160 * 1024) return set_error(CM_ERR_ARG, "policy forward: n_agents too large for the 160 KB LDS tile");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_set = 0;
+    if (cm::dev_first(attr_set)) {
         CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fwd_mfma_kernel<HEAD, KPAD, MAXMK, NW>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
     }
     const int blocks = (a.S + a.EPB - 1) / a.EPB;
     static const bool want_probe = getenv("COMMARL_FWD_PROBE") != nullptr;

@@ -794,8 +794,8 @@ extern "C" int cm_masked_agg_forward(int32_t S, int32_t N, int32_t E, const floa
     if (S <= 0) return CM_OK;
     const size_t lds = agg_lds_fwd(N, E);
     if (lds > 160 * 1024) return set_error(CM_ERR_ARG, "cm_masked_agg_forward: n_agents too large");
-    static bool once = false;
-    if (!once) { CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_fwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
+    static unsigned long long once = 0;
+    if (cm::dev_first(once)) { CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_fwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); }
     const int epb = agg_epb(N);
     const int blocks = (int)std::min<long>((S + epb - 1) / epb, 256 * 8);
     hipLaunchKernelGGL(agg_fwd_kernel<64>, dim3(blocks), dim3(TPB), lds, (hipStream_t)stream, S, N, epb, attn, dist_adj, chan, (long)ch_stride, hw, bias, out);
@@ -820,8 +820,8 @@ extern "C" int cm_masked_agg_backward(int32_t S, int32_t N, int32_t E, const flo
         return rc;
     const size_t lds = agg_lds_bwd(N, E);
     if (lds > 160 * 1024) return set_error(CM_ERR_ARG, "cm_masked_agg_backward: n_agents too large");
-    static bool once = false;
-    if (!once) { CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_bwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
+    static unsigned long long once = 0;
+    if (cm::dev_first(once)) { CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_bwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); }
     const int epb = agg_epb(N);
     const int blocks = (int)std::min<long>((S + epb - 1) / epb, 256 * 4);
     hipLaunchKernelGGL(agg_bwd_kernel<64>, dim3(blocks), dim3(TPB), lds, (hipStream_t)stream, S, N, epb, attn, dist_adj, chan, (long)ch_stride, hw, out, out_minus, d_out, d_attn, d_hw, d_bias);
@@ -840,14 +840,13 @@ extern "C" int cm_linear_wgrad(int64_t R, int32_t P, int32_t Q, const float *a, 
     const int blocks = (int)std::min<long>(chunks, 512);
     const hipStream_t st = (hipStream_t)stream;
     const int per_wave = (NT + 3) / 4;
-    static bool once = false;
-    if (!once) {
+    static unsigned long long once = 0;
+    if (cm::dev_first(once)) {
         CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        once = true;
     }
 #define CM_WG(M) hipLaunchKernelGGL(wgrad_kernel<M>, dim3(blocks), dim3(TPB), lds, st, (long)R, P, Q, a, b, c, colsum_a)
     if (per_wave <= 1) CM_WG(1); else if (per_wave <= 2) CM_WG(2); else if (per_wave <= 4) CM_WG(4);
@@ -865,8 +864,8 @@ extern "C" int cm_attention_forward(int32_t S, int32_t N, int32_t E, const float
     if (S <= 0) return CM_OK;
     const size_t lds = attn_lds(N, E);
     if (lds > 160 * 1024) return set_error(CM_ERR_ARG, "cm_attention_forward: n_agents too large");
-    static bool once = false;
-    if (!once) { CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_fwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
+    static unsigned long long once = 0;
+    if (cm::dev_first(once)) { CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_fwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); }
     const int epb = agg_epb(N);
     const int blocks = (int)std::min<long>((S + epb - 1) / epb, 256 * 8);
     hipLaunchKernelGGL(attn_fwd_kernel<64>, dim3(blocks), dim3(TPB), lds, (hipStream_t)stream, S, N, epb, q, e, m);
@@ -890,8 +889,8 @@ extern "C" int cm_attention_backward(int32_t S, int32_t N, int32_t E, const floa
     if (const int rc = attn_bwd_mfma(S, N, q, e, m, d_m, d_e_add0, d_e_add1, d_q, d_e, stream); rc != 1) return rc;
     const size_t lds = attn_lds(N, E);
     if (lds > 160 * 1024) return set_error(CM_ERR_ARG, "cm_attention_backward: n_agents too large");
-    static bool once = false;
-    if (!once) { CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_bwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
+    static unsigned long long once = 0;
+    if (cm::dev_first(once)) { CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_bwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); }
     const int epb = agg_epb(N);
     const int blocks = (int)std::min<long>((S + epb - 1) / epb, 256 * 8);
     hipLaunchKernelGGL(attn_bwd_kernel<64>, dim3(blocks), dim3(TPB), lds, (hipStream_t)stream, S, N, epb, q, e, m, d_m, d_e_add0, d_e_add1, d_q, d_e);
@@ -920,11 +919,12 @@ extern "C" int cm_gae(int32_t P, int32_t T, const float *rewards, const float *b
 extern "C" int cm_ppo_surrogate(int32_t P, int32_t T, int32_t N, int32_t A, const float *logits, const int32_t *actions,
                                 const float *old_ll, const float *adv, const int32_t *lens, float clip, float ent_coeff,
                                 int32_t add_entropy, double *total, int64_t *count, float *dlogits, void *stream) {
-    if (!logits || !actions || !old_ll || !adv || !lens || !total || !count) return set_error(CM_ERR_ARG, "cm_ppo_surrogate: null argument");
+    if (!total || !count) return set_error(CM_ERR_ARG, "cm_ppo_surrogate: null argument");
     if (A < 1 || A > PPO_MAX_A || N < 1) return set_error(CM_ERR_ARG, "cm_ppo_surrogate: 1 <= n_actions <= 8 and n_agents >= 1 required");
-    if (P <= 0 || T <= 0) return CM_OK;
-    CM_HIP(hipMemsetAsync(total, 0, sizeof(double), (hipStream_t)stream));
+    CM_HIP(hipMemsetAsync(total, 0, sizeof(double), (hipStream_t)stream));      // an empty minibatch still reports (0, 0)
     CM_HIP(hipMemsetAsync(count, 0, sizeof(int64_t), (hipStream_t)stream));
+    if (P <= 0 || T <= 0) return CM_OK;
+    if (!logits || !actions || !old_ll || !adv || !lens) return set_error(CM_ERR_ARG, "cm_ppo_surrogate: null argument");
     const long S = (long)P * T;
     hipLaunchKernelGGL(ppo_surrogate_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P, T, N, A, logits, actions,
                        old_ll, adv, lens, clip, ent_coeff, add_entropy, total, (long long *)count, dlogits);

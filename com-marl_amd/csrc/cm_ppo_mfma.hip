@@ -342,8 +342,8 @@ template <int MAXNT>
 static int launch_agg(int S, int N, const float *attn, const float *adj, const float *chan, long ch_stride, const float *hw, const float *out,
                       const float *out_minus, const float *d_out, float *d_attn, float *d_hw, float *d_bias, hipStream_t st) {
     const size_t lds = agg_lds(N);
-    static bool once = false;
-    if (!once) { CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_bwd_kernel<MAXNT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
+    static unsigned long long once = 0;
+    if (cm::dev_first(once)) { CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_bwd_kernel<MAXNT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); }
     static const int stop = [] { const char *e = getenv("COMMARL_NXN_STOP"); return e ? atoi(e) : 0; }();
     hipLaunchKernelGGL(agg_bwd_kernel<MAXNT>, dim3(blocks_for(S, lds)), dim3(TPB), lds, st, S, N, attn, adj, chan, ch_stride, hw, out, out_minus,
                        d_out, d_attn, d_hw, d_bias, stop);
@@ -355,8 +355,8 @@ template <int MAXNT>
 static int launch_attn(int S, int N, const float *q, const float *e, const float *m, const float *d_m, const float *add0, const float *add1,
                        float *d_q, float *d_e, hipStream_t st) {
     const size_t lds = attn_lds(N);
-    static bool once = false;
-    if (!once) { CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_bwd_kernel<MAXNT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
+    static unsigned long long once = 0;
+    if (cm::dev_first(once)) { CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_bwd_kernel<MAXNT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); }
     hipLaunchKernelGGL(attn_bwd_kernel<MAXNT>, dim3(blocks_for(S, lds)), dim3(TPB), lds, st, S, N, q, e, m, d_m, add0, add1, d_q, d_e);
     CM_HIP(hipGetLastError());
     return CM_OK;

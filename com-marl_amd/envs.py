@@ -131,7 +131,7 @@ class GridEnvBatch:
         h = getattr(self, "_h", None)
         if h:
             try:
-                L.lib().cm_env_destroy(h)
+                L.destroy_env(h)                        # deferred while a hipGraph capture is open
             except Exception:
                 pass
             self._h = None

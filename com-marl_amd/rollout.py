@@ -99,10 +99,10 @@ class RolloutEngine:
         self._capturing = False
         # captured chunks: one fused launch per step (cm_rollout_step) or the two-kernel form - measured per config in
         # bench.py; COMMARL_GRAPH_FUSED=0/1 forces either for A/B runs
-        import os
-        env = os.environ.get("COMMARL_GRAPH_FUSED")
-        self._fused_in_graph = bool(fused) and (env == "1" if env is not None else bool(graph_fused))
+        gf_env = os.environ.get("COMMARL_GRAPH_FUSED")
+        self._fused_in_graph = bool(fused) and (gf_env == "1" if gf_env is not None else bool(graph_fused))
         self.t = 0
+        self.generation = 0                      # bumped by reset(): a PathBatch of an earlier rollout refuses to read the buffers
 
     @property
     def step_base(self):
@@ -137,6 +137,7 @@ class RolloutEngine:
                 o["channels"] = self.channels[0][lo:hi]
             part.reset_all(out=o)
         self.t = 0
+        self.generation += 1
 
     def _step_part(self, k, t, greedy):
         part, (lo, hi) = self.parts[k], self.bounds[k]
@@ -242,37 +243,41 @@ class RolloutEngine:
         self._fused = True
         return True
 
-    def _chunk(self, n):
-        """All shards: fork, every shard's n-step chain (+ its tail) on its own stream, join.  The launches are issued
-        step by step across the shards (t outer, shard inner): a captured graph submits its nodes in capture order, so
-        issuing one shard's whole chain first would start the other shard's chain only after it (measured: ~100 us
-        stagger per replay, profiles/r02_trace_short.txt)."""
+    def _chunk(self, n, t0=0, tail=True):
+        """All shards: fork, every shard's n-step chain over slots t0 .. t0+n-1 (+ its tail) on its own stream, join.  The
+        launches are issued step by step across the shards (t outer, shard inner): a captured graph submits its nodes in
+        capture order, so issuing one shard's whole chain first would start the other shard's chain only after it
+        (measured: ~100 us stagger per replay, profiles/r02_trace_short.txt).  tail=False (the sampler's spans): no carry
+        of slot t0+n into slot 0 and no bump of the sampler's Philox base - the caller bumps once per rollout."""
         spl = int(os.environ.get("COMMARL_STEPS_PER_LAUNCH", "1"))
         if spl > 1 and self._fused is not False and self._fused_in_graph:
             # experiment: several steps per launch (cm_rollout_chunk with a short trip count) - one grid drain per spl steps
             t = 0
             while t < n:
                 m = min(spl, n - t)
-                if not self.steps_fused(t, m):
+                if not self.steps_fused(t0 + t, m):
                     raise L.CommarlError("COMMARL_STEPS_PER_LAUNCH needs the fused chunk kernel")
                 t += m
-            for k, st in enumerate(self.streams):
-                with torch.cuda.stream(st) if st is not None else _null():
-                    self._chunk_tail(k, n)
-            self.join()
+            if tail:
+                for k, st in enumerate(self.streams):
+                    with torch.cuda.stream(st) if st is not None else _null():
+                        self._chunk_tail(k, t0 + n)
+                self.join()
             return
         self.fork()
-        for t in range(n):
+        for t in range(t0, t0 + n):
             for k, st in enumerate(self.streams):
                 with torch.cuda.stream(st) if st is not None else _null():
                     self._step_part(k, t, False)
-        for k, st in enumerate(self.streams):
-            with torch.cuda.stream(st) if st is not None else _null():
-                self._chunk_tail(k, n)
+        if tail:
+            for k, st in enumerate(self.streams):
+                with torch.cuda.stream(st) if st is not None else _null():
+                    self._chunk_tail(k, t0 + n)
         self.join()
 
-    def prepare_graph(self, n=None):
-        """Capture + instantiate the hipGraph of an n-step chunk (n <= H, default H) WITHOUT advancing the rollout.
+    def prepare_graph(self, n=None, t0=0, tail=True):
+        """Capture + instantiate the hipGraph of an n-step chunk over slots t0 .. t0+n-1 (t0 + n <= H, default the whole
+        horizon) WITHOUT advancing the rollout.
         One graph holds every shard's chain as a parallel branch (fork ... join).  Measured alternatives
         (profiles/r02_steps_sweep.txt, config 2): one single-stream graph per shard replayed on the shards' own
         streams runs 37.7 us/step against 36.4 for the joint graph - independent streams start in phase, so policy
@@ -282,38 +287,46 @@ class RolloutEngine:
         One-time host-side setup that must not happen inside a capture (the weight pack, the kernels'
         hipFuncSetAttribute calls) is triggered by one scratch step whose effects are undone: the env state is
         snapshotted before and restored after it, and every trajectory slot it wrote is rewritten by the chunk itself.
-        Call it before a timed region; run_chunk() calls it on first use otherwise."""
+        Call it before a timed region; run_chunk() / run_span() call it on first use otherwise."""
         n = self.H if n is None else int(n)
-        assert 1 <= n <= self.H
-        g = self._graphs.get(n)
+        t0 = int(t0)
+        assert n >= 1 and t0 >= 0 and t0 + n <= self.H
+        key = (t0, n, bool(tail))
+        g = self._graphs.get(key)
         if g is not None:
             return g
         self.policy.sync_weights()
         if not self._graphs:                                # first capture of this engine: the scratch step
             saved = [part.get_state() for part in self.parts]
-            self._capturing = True                          # the two-launch form, exactly what the capture will issue
+            saved_slot = [b[t0:t0 + 2].clone() for b in (self.obs, self.dist_adj, self.channels) if b is not None]
+            self._capturing = True                          # the launch form the capture will issue
             try:
                 self.fork()
-                self.step(0)
+                self.step(t0)
                 self.join()
             finally:
                 self._capturing = False
             torch.cuda.synchronize(self.env.device)
             for part, st in zip(self.parts, saved):
                 part.set_state(**st)
+            # slot t0 is the chunk's INPUT when the sampler captures mid-rollout (the scratch step only wrote slot t0 + 1
+            # and the per-step outputs, all rewritten by the chunk; restoring both slots keeps the argument simple)
+            for b, keep in zip([b for b in (self.obs, self.dist_adj, self.channels) if b is not None], saved_slot):
+                b[t0:t0 + 2].copy_(keep)
         torch.cuda.synchronize(self.env.device)
         g = torch.cuda.CUDAGraph()
         self._capturing = True
         try:
-            # capture_error_mode "relaxed": calls that a capture would otherwise reject are harmless here and do happen - an
-            # env handle released by the garbage collector (cm_env_destroy -> hipFree; seen between HIP's begin / end capture
-            # in tools/trace_capture_calls.sh, where "thread_local" mode invalidated the capture depending on what ran
-            # before in the process), NCCL's watchdog thread touching HIP
-            with torch.cuda.graph(g, capture_error_mode=os.environ.get("COMMARL_CAPTURE_MODE", "relaxed")):
-                self._chunk(n)
+            # "thread_local": the capturing thread may not make a call a capture rejects, other threads (RCCL's watchdog)
+            # are not this capture's business.  The one such call this package could make - cm_env_destroy -> hipFree of a
+            # garbage-collected env handle, the cause of round 2's invalidated captures - is kept out by L.capture_guard():
+            # garbage is collected before the capture opens and handle destruction is deferred until it has closed.
+            with L.capture_guard():
+                with torch.cuda.graph(g, capture_error_mode=os.environ.get("COMMARL_CAPTURE_MODE", "thread_local")):
+                    self._chunk(n, t0, tail)
         finally:
             self._capturing = False
-        self._graphs[n] = g
+        self._graphs[key] = g
         return g
 
     def run_chunk(self, use_graph=True, n=None, weights_synced=False):
@@ -335,9 +348,21 @@ class RolloutEngine:
         if not use_graph:
             self._chunk(n)
             return
-        g = self._graphs.get(n) or self.prepare_graph(n)
+        g = self._graphs.get((0, n, True)) or self.prepare_graph(n)
         if not weights_synced:              # in-place refresh of the weight pack the graph points at; a caller that steps
             self.policy.sync_weights()      # many chunks between optimiser steps syncs once itself (~15 us of host time)
+        g.replay()
+
+    def run_span(self, t0, n, use_graph=True, weights_synced=True):
+        """Slots t0 .. t0+n-1 -> t0+1 .. t0+n, nothing else (no carry into slot 0, no Philox bump): what obtain_samples
+        strings together.  One hipGraph per (t0, n), captured on first use and reused by every later rollout of this
+        engine (the trajectory slots, the weight pack and the Philox base are fixed device addresses)."""
+        if not use_graph:
+            self._chunk(n, t0, tail=False)
+            return
+        g = self._graphs.get((t0, n, False)) or self.prepare_graph(n, t0, tail=False)
+        if not weights_synced:
+            self.policy.sync_weights()
         g.replay()
 
     def invalidate_graphs(self):

@@ -7,6 +7,7 @@ the whole loop stays on the GPU (rollout.RolloutEngine).
 (materialised to numpy only when indexed) that also exposes the device-resident trajectory and
 the (env, start, length) index, which CentralizedMAPPO consumes directly without a host trip.
 """
+import os
 import time
 from collections.abc import Sequence
 
@@ -52,7 +53,9 @@ _PATH_KEYS = ("observations", "actions", "avail_actions", "rewards", "rewards_de
 class _LazyPath(dict):
     """One path dict of the reference's format whose values are built on first access: the runner's
     ``sum(len(p['rewards']) for p in paths)`` (local_runner_wrapper.py:50-52) then costs one host copy of the reward
-    buffer instead of the whole trajectory.  It IS a dict (isinstance, ==, pickling after ``materialize()``)."""
+    buffer instead of the whole trajectory.  It IS a dict (isinstance, ==, pickling after ``materialize()``); keys a
+    caller adds (the reference's ``if 'returns' not in path: path['returns'] = ...``, centralized_ma_ppo.py:635-636) live
+    next to the lazy ones and are seen by ``in`` / ``get`` / ``keys`` / ``items`` / ``len`` / pickling."""
 
     def __init__(self, batch, i):
         super().__init__()
@@ -65,34 +68,39 @@ class _LazyPath(dict):
         dict.__setitem__(self, k, v)
         return v
 
+    def _all_keys(self):
+        return list(_PATH_KEYS) + [k for k in dict.keys(self) if k not in _PATH_KEYS]
+
     def materialize(self):
         for k in _PATH_KEYS:
             self[k]
         return self
 
     def __contains__(self, k):
-        return k in _PATH_KEYS
+        return k in _PATH_KEYS or dict.__contains__(self, k)
 
     def __iter__(self):
-        return iter(_PATH_KEYS)
+        return iter(self._all_keys())
 
     def __len__(self):
-        return len(_PATH_KEYS)
+        return len(self._all_keys())
 
     def keys(self):
-        return list(_PATH_KEYS)
+        return self._all_keys()
 
     def values(self):
-        return [self[k] for k in _PATH_KEYS]
+        return [self[k] for k in self._all_keys()]
 
     def items(self):
-        return [(k, self[k]) for k in _PATH_KEYS]
+        return [(k, self[k]) for k in self._all_keys()]
 
     def get(self, k, default=None):
-        return self[k] if k in _PATH_KEYS else default
+        return self[k] if k in self else default
 
     def __eq__(self, other):
         return dict(self.items()) == (dict(other.items()) if isinstance(other, _LazyPath) else other)
+
+    __hash__ = None
 
     def __reduce__(self):
         return (dict, (dict(self.items()),))
@@ -115,6 +123,8 @@ class PathBatch(Sequence):
         self._bufs = {}                       # engine buffer name -> numpy (host copies made so far)
         self._idx = None
         self._T = None
+        self._paths = {}                      # index -> the ONE _LazyPath of that path (keys a caller sets on it persist)
+        self._generation = getattr(engine, "generation", None)
 
     def __len__(self):
         return int(self.length.numel())
@@ -136,6 +146,9 @@ class PathBatch(Sequence):
 
     def _buf(self, name):
         if name not in self._bufs:
+            if self._generation != getattr(self.engine, "generation", None):
+                raise RuntimeError("this PathBatch belongs to an earlier rollout: the engine's trajectory buffers were "
+                                   "overwritten by a later obtain_samples / reset (materialize() the paths you keep)")
             self._index()
             t = getattr(self.engine, name)
             extra = 1 if name in ("obs", "dist_adj", "channels") else 0
@@ -149,10 +162,13 @@ class PathBatch(Sequence):
             i += len(self)
         if not 0 <= i < len(self):
             raise IndexError(i)
-        return _LazyPath(self, i)
+        p = self._paths.get(i)
+        if p is None:
+            p = self._paths[i] = _LazyPath(self, i)
+        return p
 
     def __iter__(self):
-        return (_LazyPath(self, i) for i in range(len(self)))
+        return (self[i] for i in range(len(self)))
 
     def _build(self, i, key):
         env_idx, start, length = self._index()
@@ -286,16 +302,24 @@ class CentralizedMAOnPolicyVectorizedSampler:
         eng._pol_share = t_pol / max(t_pol + t_env, 1e-9)
         return eng._pol_share
 
-    def obtain_samples(self, itr, batch_size=None, whole_paths=True, chunk=32):
-        """Roll until the completed paths hold >= batch_size agent-steps (:119), checking the stop
-        rule once per `chunk` steps on the device; returns the completed paths up to the exact step
-        at which the reference loop would have stopped."""
+    def obtain_samples(self, itr, batch_size=None, whole_paths=True, chunk=16, use_graph=None):
+        """Roll until the completed paths hold >= batch_size agent-steps (:119), checking the stop rule once per `chunk`
+        steps on the device; returns the completed paths up to the exact step at which the reference loop would have
+        stopped.  The stepping loop replays one captured hipGraph per `chunk`-step span of trajectory slots
+        (RolloutEngine.run_span; captured on the first rollout of an engine, reused by every later one) - eager
+        stepping (``use_graph=False`` / COMMARL_SAMPLER_GRAPH=0) gives the same PathBatch, 2.3x slower at the headline
+        config.  No check happens before step batch_size / (B N): the completed paths cannot hold the batch earlier."""
         mpl = self.algo.max_path_length
         B, N = self._n_envs, self._n_agents
         if not batch_size:
             batch_size = mpl * B
+        if use_graph is None:
+            use_graph = os.environ.get("COMMARL_SAMPLER_GRAPH", "1") != "0"
+        chunk = max(1, int(chunk))
         # after t steps the completed paths hold >= B*N*(t - mpl) samples  =>  t <= batch/(B*N) + mpl
-        horizon = int(np.ceil(batch_size / (B * N))) + mpl
+        t_min = int(np.ceil(batch_size / (B * N)))
+        bound = t_min + mpl
+        horizon = -(-bound // chunk) * chunk                       # whole spans: a rollout may run past its stop step
         eng = self._ensure_engine(horizon)
         policy = self.algo.policy
         policy.sync_weights()
@@ -306,20 +330,31 @@ class CentralizedMAOnPolicyVectorizedSampler:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
         t, stop_t = 0, None
+        counted, base = 0, 0                                       # steps whose completed samples are in `base` already
         while stop_t is None:
-            t1 = min(t + chunk, horizon)
-            for k in range(t, t1):
-                eng.step(k)
-            eng.join()
-            # stop rule on device: first step at which cumulative completed samples >= batch_size
-            done_samples = eng.path_len[:t1].sum(dim=1, dtype=torch.int64).cumsum(0) * N
-            hit = torch.nonzero(done_samples >= batch_size)
-            if hit.numel():
-                stop_t = int(hit[0].item()) + 1
-            elif t1 >= horizon:
-                raise RuntimeError("sampler horizon exhausted before batch_size was reached (bug in the bound)")
+            t1 = min(t + chunk, eng.H)
+            if use_graph:
+                eng.run_span(t, t1 - t)
+            else:
+                for k in range(t, t1):
+                    eng.step(k)
+                eng.join()
+            if t1 >= t_min:
+                # stop rule on device: first step at which cumulative completed samples >= batch_size (one host read)
+                cs = eng.path_len[counted:t1].sum(dim=1, dtype=torch.int64).cumsum(0) * N + base
+                hit = cs >= batch_size
+                first, last = torch.stack([torch.where(hit.any(), hit.to(torch.int64).argmax(), hit.new_full((), -1, dtype=torch.int64)),
+                                           cs[-1]]).tolist()
+                if first >= 0:
+                    stop_t = counted + first + 1
+                elif t1 >= eng.H:
+                    raise RuntimeError("sampler horizon exhausted before batch_size was reached (bug in the bound)")
+                counted, base = t1, last
             t = t1
         ev1.record()
+        # fresh action-sampling draws for the next rollout (the reference's generator simply keeps advancing): every draw
+        # a returned path used sits at a policy step < stop_t <= bound, whatever the span length was
+        eng.bump(bound)
         self.batch.check_status()
         T = stop_t
         # completed paths within [0, T): every (t, b) with path_len > 0
@@ -336,6 +371,33 @@ class CentralizedMAOnPolicyVectorizedSampler:
         tabular.record('ProcessExecTime', max(total - gpu, 0.0))   # host-side bookkeeping around the device loop
         tabular.record('BoundReturn', float(getattr(self._base, "bound_return", 0.0)))
         self.last_steps = T
-        if not whole_paths:
-            raise NotImplementedError("whole_paths=False (truncate_paths) is unused by the runners")
-        return paths
+        self.last_steps_run = t
+        return paths if whole_paths else truncate_paths(paths, batch_size)
+
+
+def truncate_paths(paths, max_samples):
+    """What ``whole_paths=False`` does in the reference (sampler :245 -> garage/sampler/utils.py:91-140): keep the shortest
+    prefix of paths holding >= max_samples steps, then cut the last kept path to the exact count - but only the keys
+    observations / actions / rewards / env_infos / agent_infos are accepted there, and the Com-MARL path dicts carry more
+    (:206-221), so the reference raises ValueError at the first other key ('avail_actions', third in the dict).  Same
+    outcome here, key order included; no runner passes whole_paths=False."""
+    accepted_arrays, accepted_dicts = ('observations', 'actions', 'rewards'), ('env_infos', 'agent_infos')
+    lens = [len(p['rewards']) for p in paths]
+    keep = len(lens)
+    while keep > 0 and sum(lens[:keep - 1]) >= max_samples:       # paths beyond the prefix that already holds the batch
+        keep -= 1
+    out = [paths[i] for i in range(keep)]
+    if not out:
+        return out
+    cut = max_samples - sum(lens[:keep - 1])                      # steps the last kept path may contribute
+    last, short = out[-1], {}
+    for key in last.keys():
+        if key in accepted_arrays:
+            short[key] = last[key][:cut]
+        elif key in accepted_dicts:
+            short[key] = {k: (None if v is None else v[:cut]) for k, v in last[key].items()}
+        else:
+            raise ValueError('Unexpected key {} found in path. Valid keys: {}'.format(
+                key, set(accepted_arrays + accepted_dicts)))
+    out[-1] = short
+    return out

@@ -362,3 +362,22 @@ def test_paths_replay_of_the_reference_runner_contract():
     q = pickle.loads(pickle.dumps(p0))
     assert type(q) is dict and set(q) == set(p0.keys())
     np.testing.assert_array_equal(q["actions"], p0["actions"])
+
+
+def test_truncate_paths_walks_like_the_reference():
+    """whole_paths=False (sampler :245 -> garage/sampler/utils.py:91-140): trailing paths beyond the batch are dropped, the
+    last kept path is cut - and a path dict with Com-MARL's extra keys raises the reference's ValueError."""
+    import numpy as np
+    import pytest
+    from com_marl_amd.sampler import truncate_paths
+    mk = lambda n: dict(observations=np.zeros((n, 3)), actions=np.zeros((n, 2)), rewards=np.arange(n, dtype=np.float64),   # noqa: E731
+                        env_infos=dict(a=np.zeros(n)), agent_infos=dict(p=np.zeros((n, 2, 5))))
+    out = truncate_paths([mk(5), mk(4), mk(6), mk(2)], 11)
+    assert [len(p['rewards']) for p in out] == [5, 4, 2] and out[-1]['agent_infos']['p'].shape == (2, 2, 5)
+    out = truncate_paths([mk(5), mk(4)], 100)
+    assert [len(p['rewards']) for p in out] == [5, 4]
+    assert truncate_paths([], 5) == []
+    bad = mk(4)
+    bad = dict(observations=bad['observations'], actions=bad['actions'], avail_actions=np.ones((4, 10)), rewards=bad['rewards'])
+    with pytest.raises(ValueError, match="Unexpected key avail_actions found in path"):
+        truncate_paths([mk(3), bad], 5)
