@@ -23,6 +23,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+F16_SPLIT_PEAK = 157.3 * 256.0 / 48.0       # TFLOP/s f32-equivalent of the f16-split scheme: 3 x 16 clk against 8 x 32 clk
+
 CONFIGS = {
     # BASELINE.json configs[1] - the configuration the metric is quoted on
     "pp_map10": dict(scenario="pp", map=10, sen=1, n_agents=4, n_preys=4, load=2, max_env_steps=200, loss=0.0,
@@ -150,69 +152,18 @@ def cpu_baseline(c, seed, budget_s=12.0, kind="commdp"):
                        f"OpenMP over envs), {dt:.1f} s")
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--config", default="pp_map10", choices=sorted(CONFIGS))
-    ap.add_argument("--envs", type=int, default=None, help="envs per GPU (default: the config's)")
-    ap.add_argument("--chunk", type=int, default=50, help="steps per captured hipGraph")
-    ap.add_argument("--streams", type=int, default=None,
-                    help="independent env shards per GPU, one HIP stream each (default: the config's, normally 2)")
-    ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-train-loop", action="store_true")
-    ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--policy", default="commdp", choices=["commdp", "obsdp", "cent"],
-                    help="Comm-DP GNN policy (the headline) or the reference's Obs-DP / CENT variants (SURVEY.md §8f-2)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak: the config's env batch on EVERY GPU (default); strong: the batch split over the GPUs "
-                         "(SURVEY.md §8e: 4096 -> 4096/2048/1024/512 envs per GPU)")
-    args = ap.parse_args()
-
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # `python bench.py --gpus N` without a launcher: start N fresh ranks (one per GPU) and relay rank 0's line.
-        # Nothing in this process has touched the GPU yet, and the ranks are children, never a re-exec.
-        import socket
-        import subprocess
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        raise SystemExit(subprocess.run(cmd, env=env).returncode)
-
+def measure_rollout(config, args, rank, world, dev, steps, warmup, envs=None, streams=None):
+    """One config on this rank's GPU: K steps of the rollout under the timing contract (every graph captured, instantiated
+    and replayed before t0; barrier + synchronize on both sides; max over ranks), then the per-kernel durations with HIP
+    events and the roofline rows.  Returns everything main() puts into the JSON line."""
     import numpy as np
     import torch
     import torch.distributed as dist
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
-                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs the MI355X; there is no CPU path")
-    # one rank per GPU; COMMARL_DIST_BACKEND=gloo lets several ranks share one GPU to rehearse the N>1 path
-    backend = os.environ.get("COMMARL_DIST_BACKEND", "nccl")
-    dev = torch.device("cuda", local % torch.cuda.device_count())
-    torch.cuda.set_device(dev)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
-
-    from com_marl_amd import envs as E, nets
+    from com_marl_amd import envs as E, nets  # noqa: F401
     from com_marl_amd.rollout import RolloutEngine
 
-    c = dict(CONFIGS[args.config])
-    B = args.envs or c["envs"]
+    c = dict(CONFIGS[config])
+    B = envs or c["envs"]
     if args.scaling == "strong":                        # the batch is split: rank r owns global envs [r*B/k, (r+1)*B/k)
         if B % world:
             raise SystemExit(f"--scaling strong: {B} envs do not split over {world} GPUs")
@@ -224,10 +175,10 @@ def main():
     # first inside every chunk graph and the two stay out of phase; a timed region of a few ms cannot amortise that
     # start-up stagger (--steps 20 at config 2: 42 us/step as one shard, 45 as two; profiles/r02_steps_sweep.txt), so
     # short runs use one shard.
-    if args.streams is not None:
-        n_streams = args.streams
+    if streams is not None:
+        n_streams = streams
     else:
-        n_streams = 1 if args.steps * c["step_us"] < 10_000 else c.get("streams", 2)
+        n_streams = 1 if steps * c["step_us"] < 10_000 else c.get("streams", 2)
     ns = n_streams if (n_streams > 1 and B % n_streams == 0) else 1
     if ns > 1:      # the same B envs (same global ids, same Philox streams) as `ns` shards, each on its own stream
         shards = [E.GridEnvBatch(c["scenario"], env_params(c), B // ns, device=dev, seed=args.seed,
@@ -238,7 +189,7 @@ def main():
     torch.manual_seed(args.seed)                       # replicas: identical weights on every rank
     policy = make_policy(args.policy, spec, env.N, dev)
     policy.set_rng(args.seed, env_id_offset=rank * B)
-    G = max(1, min(args.chunk, args.steps))             # steps per captured hipGraph
+    G = max(1, min(args.chunk, steps))             # steps per captured hipGraph
     eng = RolloutEngine(shards, policy, horizon=G, persistent=os.environ.get("COMMARL_PERSISTENT", "0") == "1")
     eng.reset()
     use_graph = not args.no_graph
@@ -260,12 +211,12 @@ def main():
     # Every graph the timed region replays is captured, instantiated AND replayed once before t0 (capture does not
     # advance the rollout; the warm-up below is W steps through the same chunk machinery, plus one replay of any
     # timed-region graph length the W steps did not already use).
-    timed_lengths = sorted(set(plan(args.steps)))
+    timed_lengths = sorted(set(plan(steps)))
     if use_graph:
         for k in timed_lengths:
             eng.prepare_graph(k)
-    run(args.warmup)
-    extra_warm = [k for k in timed_lengths if k not in set(plan(args.warmup))]
+    run(warmup)
+    extra_warm = [k for k in timed_lengths if k not in set(plan(warmup))]
     for k in extra_warm:
         eng.run_chunk(use_graph=use_graph, n=k)
     n_captured = len(eng._graphs)
@@ -273,7 +224,7 @@ def main():
     policy.sync_weights()
     barrier()
     t0 = time.perf_counter()
-    run(args.steps)
+    run(steps)
     t_issue = time.perf_counter() - t0
     barrier()
     dt = time.perf_counter() - t0
@@ -285,7 +236,7 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    value = world * B * args.steps / dt
+    value = world * B * steps / dt
 
     # ---- per-kernel durations with HIP events on the launch stream.  The launches are replayed from a
     # captured hipGraph of `inner` back-to-back launches (as in the timed region), so the figure is the
@@ -294,9 +245,11 @@ def main():
         fn()
         torch.cuda.synchronize(dev)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, capture_error_mode="relaxed"):   # as RolloutEngine.prepare_graph: stray hipFree / NCCL watchdog calls are harmless
-            for _ in range(inner):
-                fn()
+        from com_marl_amd import _lib as L
+        with L.capture_guard():                     # as RolloutEngine.prepare_graph: no hipFree can land inside the capture
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                for _ in range(inner):
+                    fn()
         g.replay()
         torch.cuda.synchronize(dev)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -332,11 +285,12 @@ def main():
     if args.policy != "commdp":                         # no mask reads, no attention output
         b_pol = 4 * env.N * env.d + 4 * env.N + 20 * env.N
     kname = "cm_policy_forward" if args.policy == "commdp" else "cm_mlp_policy_forward"
+    f16_pipe = args.policy == "commdp" and os.environ.get("COMMARL_POLICY_KERNEL", "h") not in ("f32", "valu")
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath) and B == CONFIGS[args.config]["envs"]:      # PMC figures are per launch of the default batch
+    if os.path.exists(tpath) and B == CONFIGS[config]["envs"]:      # PMC figures are per launch of the default batch
         try:
-            traffic = json.load(open(tpath)).get(args.config)
+            traffic = json.load(open(tpath)).get(config)
         except Exception:
             traffic = None
 
@@ -348,6 +302,8 @@ def main():
         row = dict(bound=bound, us=t * 1e6, hbm_GBps=gbs, hbm_frac=gbs / 8000.0, algorithmic_bytes=nbytes)
         if bound == "mfma":
             row.update(achieved=tf, peak=157.3, unit="TFLOP/s", frac=tf / 157.3, flops=fl)
+            if f16_pipe:                            # the instructions actually issued: 3 f16 MFMAs of 16 clk per 16x16x32 block
+                row.update(frac_f16_pipe=tf / F16_SPLIT_PEAK)   # against 8 f32 MFMAs of 32 clk -> ceiling 157.3 x 256 / 48
         else:
             row.update(achieved=gbs, peak=8000.0, unit="GB/s", frac=gbs / 8000.0)
         return row
@@ -356,22 +312,106 @@ def main():
         kernels["cm_rollout_step"] = kernel_row("mfma", t_fused, flops, (b_env + b_pol) * B)
     # the dominant kernel of the TIMED REGION: the fused rollout step when the chunks were captured with it
     dom = "cm_rollout_step" if t_fused is not None else (kname if t_pol >= t_env else "cm_env_step")
+    tr = (traffic or {}).get(dom) if isinstance(traffic, dict) else None
     roofline = dict(kernel=dom, **{k: kernels[dom][k] for k in ("bound", "achieved", "peak", "unit", "frac", "hbm_frac")},
-                    traffic=(traffic or {}).get(dom) if isinstance(traffic, dict) else None,
-                    note=("peak = dense f32 MFMA (the arithmetic is f32-grade: each 16x16x32 block runs as three "
-                          "v_mfma_f32_16x16x32_f16 on (hi, lo) operand pairs, DESIGN.md §4); achieved = algorithmic FLOPs / "
-                          "HIP-event time of graph-replayed back-to-back launches of the whole per-GPU batch"),
+                    traffic=tr,
+                    traffic_source=(None if tr is None else
+                                    "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of a builder run on "
+                                    "another MI355X box (not measured by this run); raw counter values, the guide's gfx950 x2 "
+                                    "FETCH_SIZE rule for 16-byte-per-lane reads NOT applied (it would put traffic at <= 1.6x "
+                                    "the algorithmic bytes instead of 1.13x)"),
+                    note=("peak = dense f32 MFMA (the arithmetic is f32-grade); the instructions issued are three "
+                          "v_mfma_f32_16x16x32_f16 per 16x16x32 block on (hi, lo) operand pairs (DESIGN.md §4), whose own ceiling "
+                          "is 157.3 x 256/48 = 839 TFLOP/s f32-equivalent: frac_f16_pipe prices the kernel on THAT pipe; "
+                          "achieved = algorithmic FLOPs / HIP-event time of graph-replayed back-to-back launches of the whole "
+                          "per-GPU batch"),
                     kernels=kernels,
-                    hot_path=dict(bound="hbm", achieved=(b_env + b_pol) * B * args.steps / dt / 1e9 / world, peak=8000.0,
-                                  unit="GB/s", frac=(b_env + b_pol) * B * args.steps / dt / 1e9 / world / 8000.0,
+                    hot_path=dict(bound="hbm", achieved=(b_env + b_pol) * B * steps / dt / 1e9 / world, peak=8000.0,
+                                  unit="GB/s", frac=(b_env + b_pol) * B * steps / dt / 1e9 / world / 8000.0,
                                   bytes_per_env_step=b_env + b_pol))
+
+    if "frac_f16_pipe" in kernels[dom]:
+        roofline["frac_f16_pipe"] = kernels[dom]["frac_f16_pipe"]
+    return dict(c=c, B=B, env=env, policy=policy, spec=spec, eng=eng, ns=ns, G=G, value=value, dt=dt, n_captured=n_captured,
+                timed_lengths=timed_lengths, extra_warm=extra_warm, use_graph=use_graph, roofline=roofline)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--config", default="pp_map10", choices=sorted(CONFIGS))
+    ap.add_argument("--envs", type=int, default=None, help="envs per GPU (default: the config's)")
+    ap.add_argument("--chunk", type=int, default=50, help="steps per captured hipGraph")
+    ap.add_argument("--streams", type=int, default=None,
+                    help="independent env shards per GPU, one HIP stream each (default: the config's, normally 2)")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-loop", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="skip the BASELINE configs 3-5 that a default single-GPU run times after the headline")
+    ap.add_argument("--extra-steps", type=int, default=600, help="timed steps of each extra config")
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--policy", default="commdp", choices=["commdp", "obsdp", "cent"],
+                    help="Comm-DP GNN policy (the headline) or the reference's Obs-DP / CENT variants (SURVEY.md §8f-2)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: the config's env batch on EVERY GPU (default); strong: the batch split over the GPUs "
+                         "(SURVEY.md §8e: 4096 -> 4096/2048/1024/512 envs per GPU)")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start N fresh ranks (one per GPU) and relay rank 0's line.
+        # Nothing in this process has touched the GPU yet, and the ranks are children, never a re-exec.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs the MI355X; there is no CPU path")
+    # one rank per GPU; COMMARL_DIST_BACKEND=gloo lets several ranks share one GPU to rehearse the N>1 path
+    backend = os.environ.get("COMMARL_DIST_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()
+    if backend == "nccl" and world > n_dev:
+        raise SystemExit(f"bench.py: {world} ranks but {n_dev} GPU(s) visible - RCCL needs one card per rank "
+                         "(COMMARL_DIST_BACKEND=gloo rehearses the N>1 path on fewer cards and says so in its line)")
+    rehearsal = world > n_dev                           # several ranks share a card: NOT an N-GPU measurement
+    dev = torch.device("cuda", local % n_dev)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+
+    m = measure_rollout(args.config, args, rank, world, dev, args.steps, args.warmup, envs=args.envs, streams=args.streams)
+    c, B, env, policy, spec, eng, ns, G, value, dt = (m[k] for k in ("c", "B", "env", "policy", "spec", "eng", "ns", "G", "value", "dt"))
+    n_captured, timed_lengths, extra_warm, use_graph, roofline = (m[k] for k in ("n_captured", "timed_lengths", "extra_warm", "use_graph", "roofline"))
 
     out = {
         # BASELINE.json's metric for the headline config; rollout = fused policy forward + sample + env step + auto-reset
         "metric": ("env-steps/sec (whole node), PredatorPrey M=10 N=4, 4096 envs at 1/2/4/8 GPUs"
                    if (args.config == "pp_map10" and args.policy == "commdp")
                    else f"env-steps/sec (whole node), {args.config}, {args.policy} policy"),
-        "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": value, "unit": "env-steps/s", "n_gpus": min(world, n_dev), "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": (c["label"] if args.policy == "commdp" else c["label"].replace(
@@ -388,16 +428,49 @@ def main():
                    "parallelism": f"env-sharded x{world} (no data-path collective in the rollout)"},
         "roofline": roofline,
     }
+    if rehearsal:       # gloo ranks sharing cards: the N>1 code path runs, the number says nothing about N GPUs
+        out.update(rehearsal=True, ranks=world, backend=backend)
+    # BASELINE configs 3-5 on the same clock (single-GPU default run only): same contract - graphs captured and replayed
+    # before t0, synchronize on both sides - with fewer steps; each entry carries its own roofline rows
+    if (world == 1 and rank == 0 and args.config == "pp_map10" and args.policy == "commdp" and args.envs is None
+            and not args.no_extra_configs and not args.no_graph):
+        del m
+        extras = {}
+        for name in ("co_map20", "pp_map30", "co_map30"):
+            try:
+                torch.cuda.synchronize(dev)
+                x = measure_rollout(name, args, rank, world, dev, args.extra_steps, 100)
+                extras[name] = {"workload": x["c"]["label"], "envs_per_gpu": x["B"], "n_agents": x["c"]["n_agents"],
+                                "obs_dim": x["env"].d, "steps": args.extra_steps, "warmup": 100, "streams": x["ns"],
+                                "value": x["value"], "unit": "env-steps/s", "ms_per_step": x["dt"] / args.extra_steps * 1e3,
+                                "step_launches": 1 if (x["eng"]._fused_in_graph and x["eng"]._fused) else 2,
+                                "roofline": x["roofline"]}
+                del x
+            except Exception as e:              # an extra leg never takes the headline line down
+                extras[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        out["configs"] = extras
     if rank == 0 and world == 1 and not args.no_cpu_baseline:     # the CPU leg is a single-GPU-run extra (its OpenMP team
         out["cpu_baseline"] = cpu_baseline(c, args.seed, kind=args.policy)   # would compete with the other ranks' host threads)
     if not args.no_train_loop:
         try:
             from com_marl_amd.train_bench import train_loop_measurement
             out["train_loop"] = train_loop_measurement(env, policy, c, spec, world, rank, dev, args.seed, kind=args.policy)
+            # the same loop at the REFERENCE's epoch size (exp_runners/env_uitils.py:13: 60000 N / 8 agent-steps = 30 000 at
+            # N = 4, i.e. 7 500 env-steps; the reference collects them with n_envs = 1): 64 envs here, so an epoch is ~120
+            # rollout steps + 30 optimiser steps over ~40 paths - the launch-bound end of the update
+            if world == 1 and args.policy == "commdp" and args.config == "pp_map10" and args.envs is None:
+                from com_marl_amd import envs as E
+                small = E.GridEnvBatch(c["scenario"], env_params(c), 64, device=dev, seed=args.seed)
+                r = train_loop_measurement(small, policy, c, spec, world, rank, dev, args.seed, epochs=3, kind=args.policy,
+                                           batch_size=60000 * c["n_agents"] // 8)
+                r["note"] = "reference epoch size: 30 000 agent-steps (7 500 env-steps) per epoch from 64 envs"
+                out["train_loop_reference_batch"] = r
         except ImportError:
             out["train_loop"] = None
         except Exception as e:                      # the headline (rollout) line must survive a failure of this extra leg
-            out["train_loop"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            out.setdefault("train_loop", {"error": f"{type(e).__name__}: {e}"[:300]})
+            if "error" not in (out["train_loop"] or {}):
+                out["train_loop_reference_batch"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -99,7 +99,10 @@ static int dispatch_h(const FwdArgs &a, const TrunkH &tw, const PolHeadH &ph, co
 
 // ---- operand pack: Wt [K][OUT] f32 (the ABI's transposed weights) -> A fragments of the transposed layer ----------
 // dst uint4 index ((ct * KB + q) * 2 + plane) * 64 + lane = halves e = 0..7 of W[o = 16 ct + (lane & 15)][k = 32 q + 8 (lane >> 4) + e]
-__global__ void pack_layer_h_kernel(const float *__restrict__ Wt, int K, int OUT, int KB, int CT, uint4 *__restrict__ dst) {
+// *bad is raised when a weight cannot be carried by the (hi, lo) f16 pair: |w| > 65504 (the largest f16), inf or NaN would
+// turn into +-inf planes silently - cm_policy_pack / cm_critic_pack refuse such a net (pack_range_check below)
+__global__ void pack_layer_h_kernel(const float *__restrict__ Wt, int K, int OUT, int KB, int CT, uint4 *__restrict__ dst,
+                                    int *__restrict__ bad) {
     const int idx = blockIdx.x * 256 + threadIdx.x;                       // one (ct, q, lane): both planes
     if (idx >= CT * KB * 64) return;
     const int lane = idx & 63, blk = idx >> 6, q = blk % KB, ct = blk / KB;
@@ -109,6 +112,7 @@ __global__ void pack_layer_h_kernel(const float *__restrict__ Wt, int K, int OUT
     for (int e = 0; e < 8; ++e) {
         const int k = k0 + e;
         const float w = (k < K && o < OUT) ? Wt[(size_t)k * OUT + o] : 0.0f;
+        if (bad && !(fabsf(w) <= 65504.0f)) atomicOr(bad, 1);
         h16 h, l;
         split2(w, h, l);
         hi[e] = h; lo[e] = l;
@@ -117,22 +121,59 @@ __global__ void pack_layer_h_kernel(const float *__restrict__ Wt, int K, int OUT
     dst[((size_t)blk * 2 + 1) * 64 + lane] = __builtin_bit_cast(uint4, lo);
 }
 
-static int pack_one_h(const float *Wt, int K, int OUT, int kp, int out_pad, uint4 *dst, void *stream) {
+// One range flag per device: a device word the pack kernels raise and a pinned host word it is copied into.
+struct RangeFlag { int *dev = nullptr, *host = nullptr; };
+static RangeFlag *range_flag() {
+    static RangeFlag flags[64];
+    static const bool on = [] { const char *e = getenv("COMMARL_PACK_CHECK"); return !(e && e[0] == '0'); }();
+    if (!on) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    RangeFlag &f = flags[dev & 63];
+    if (!f.dev) {
+        if (hipMalloc(&f.dev, sizeof(int)) != hipSuccess) { f.dev = nullptr; return nullptr; }
+        if (hipHostMalloc(&f.host, sizeof(int), hipHostMallocDefault) != hipSuccess) { (void)hipFree(f.dev); f.dev = nullptr; return nullptr; }
+    }
+    return &f;
+}
+// Opens a checked pack: clears the flag on `stream`; nullptr (no check) while the stream is being captured - a capture cannot
+// wait for the device - or with COMMARL_PACK_CHECK=0.
+static int *range_check_begin(void *stream) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing((hipStream_t)stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+    RangeFlag *f = range_flag();
+    if (!f) return nullptr;
+    if (hipMemsetAsync(f->dev, 0, sizeof(int), (hipStream_t)stream) != hipSuccess) return nullptr;
+    return f->dev;
+}
+// Closes it: one small copy + a wait for the pack kernels (a pack happens once per weight update, not per step).
+static int range_check_end(int *bad, void *stream, const char *what) {
+    if (!bad) return CM_OK;
+    RangeFlag *f = range_flag();
+    CM_HIP(hipMemcpyAsync(f->host, f->dev, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    CM_HIP(hipStreamSynchronize((hipStream_t)stream));
+    if (*f->host)
+        return set_error(CM_ERR_ARG, std::string(what) + ": a weight lies outside the f16 range (|w| > 65504, inf or NaN) - the f16-split "
+                                     "matrix-core kernels cannot carry it; COMMARL_POLICY_KERNEL=f32 selects the all-f32 kernels");
+    return CM_OK;
+}
+
+static int pack_one_h(const float *Wt, int K, int OUT, int kp, int out_pad, uint4 *dst, void *stream, int *bad) {
     if (!Wt) return set_error(CM_ERR_ARG, "weight pack: null layer weight");
     const int KB = kp / 32, CT = out_pad / 16, total = CT * KB * 64;
-    hipLaunchKernelGGL(pack_layer_h_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, Wt, K, OUT, KB, CT, dst);
+    hipLaunchKernelGGL(pack_layer_h_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, Wt, K, OUT, KB, CT, dst, bad);
     CM_HIP(hipGetLastError());
     return CM_OK;
 }
 
 static int pack_trunk_h(int d, int L, const float *w1t, const float *w2t, const float *wat, const float *gw, int kh,
-                        const PackLayoutH &lo, uint4 *pack, void *stream) {
-    if (int rc = pack_one_h(w1t, d, EH, kh, EH, pack + lo.enc1, stream)) return rc;
-    if (int rc = pack_one_h(w2t, EH, EMB, EH, EMB, pack + lo.enc2, stream)) return rc;
-    if (int rc = pack_one_h(wat, EMB, EMB, EMB, EMB, pack + lo.attn, stream)) return rc;
+                        const PackLayoutH &lo, uint4 *pack, void *stream, int *bad) {
+    if (int rc = pack_one_h(w1t, d, EH, kh, EH, pack + lo.enc1, stream, bad)) return rc;
+    if (int rc = pack_one_h(w2t, EH, EMB, EH, EMB, pack + lo.enc2, stream, bad)) return rc;
+    if (int rc = pack_one_h(wat, EMB, EMB, EMB, EMB, pack + lo.attn, stream, bad)) return rc;
     const size_t per = LayerH<EMB, EMB>::PACK_U4;
     for (int l = 0; l < L; ++l)
-        if (int rc = pack_one_h(gw ? gw + (size_t)l * EMB * EMB : nullptr, EMB, EMB, EMB, EMB, pack + lo.gcn + (size_t)l * per, stream)) return rc;
+        if (int rc = pack_one_h(gw ? gw + (size_t)l * EMB * EMB : nullptr, EMB, EMB, EMB, EMB, pack + lo.gcn + (size_t)l * per, stream, bad)) return rc;
     return CM_OK;
 }
 
@@ -154,11 +195,13 @@ int policy_pack_h(const cm_policy_weights *w, void *dst, void *stream) {
     if (!kh) return CM_OK;                               // no f16 instantiation for this obs dim: nothing to pack
     const mh::PackLayoutH lo = mh::pack_layout_h(kh, w->n_hops, true);
     uint4 *pack = reinterpret_cast<uint4 *>(dst);
-    if (int rc = mh::pack_trunk_h(w->d, w->n_hops, w->enc_w1t, w->enc_w2t, w->attn_wt, w->gcn_w, kh, lo, pack, stream)) return rc;
-    if (int rc = mh::pack_one_h(w->hd_w1t, mf::EMB, mf::H1, mf::EMB, mf::H1, pack + lo.x1, stream)) return rc;
-    if (int rc = mh::pack_one_h(w->hd_w2t, mf::H1, mf::H2, mf::H1, mf::H2, pack + lo.h2, stream)) return rc;
-    if (int rc = mh::pack_one_h(w->hd_w3t, mf::H2, mf::H3, mf::H2, mf::H3, pack + lo.h3, stream)) return rc;
-    return mh::pack_one_h(w->hd_w4t, mf::H3, w->n_act, mf::H3, 16, pack + lo.h4, stream);
+    int *bad = mh::range_check_begin(stream);
+    if (int rc = mh::pack_trunk_h(w->d, w->n_hops, w->enc_w1t, w->enc_w2t, w->attn_wt, w->gcn_w, kh, lo, pack, stream, bad)) return rc;
+    if (int rc = mh::pack_one_h(w->hd_w1t, mf::EMB, mf::H1, mf::EMB, mf::H1, pack + lo.x1, stream, bad)) return rc;
+    if (int rc = mh::pack_one_h(w->hd_w2t, mf::H1, mf::H2, mf::H1, mf::H2, pack + lo.h2, stream, bad)) return rc;
+    if (int rc = mh::pack_one_h(w->hd_w3t, mf::H2, mf::H3, mf::H2, mf::H3, pack + lo.h3, stream, bad)) return rc;
+    if (int rc = mh::pack_one_h(w->hd_w4t, mf::H3, w->n_act, mf::H3, 16, pack + lo.h4, stream, bad)) return rc;
+    return mh::range_check_end(bad, stream, "cm_policy_pack");
 }
 
 int critic_pack_h(const cm_critic_weights *w, void *dst, void *stream) {
@@ -166,8 +209,10 @@ int critic_pack_h(const cm_critic_weights *w, void *dst, void *stream) {
     if (!kh) return CM_OK;
     const mh::PackLayoutH lo = mh::pack_layout_h(kh, w->n_hops, false);
     uint4 *pack = reinterpret_cast<uint4 *>(dst);
-    if (int rc = mh::pack_trunk_h(w->d, w->n_hops, w->enc_w1t, w->enc_w2t, w->attn_wt, w->gcn_w, kh, lo, pack, stream)) return rc;
-    return mh::pack_one_h(w->dec_w1t, mf::EMB, mf::DH, mf::EMB, mf::DH, pack + lo.x1, stream);
+    int *bad = mh::range_check_begin(stream);
+    if (int rc = mh::pack_trunk_h(w->d, w->n_hops, w->enc_w1t, w->enc_w2t, w->attn_wt, w->gcn_w, kh, lo, pack, stream, bad)) return rc;
+    if (int rc = mh::pack_one_h(w->dec_w1t, mf::EMB, mf::DH, mf::EMB, mf::DH, pack + lo.x1, stream, bad)) return rc;
+    return mh::range_check_end(bad, stream, "cm_critic_pack");
 }
 
 // h_pack = the f16 operand pack (behind the f32 one in the caller's pack buffer).  Returns 1 when this shape has no

@@ -503,8 +503,9 @@ class _WeightPack:
                 if v is not None:
                     o, n = offs[k]
                     buf[o:o + n].copy_(v.detach().to(torch.float32).reshape(-1))
-            self._pack_sig = sig
+            self._pack_sig = None                               # a refused pack (cm_*_pack: weight outside the f16 range) is retried
             self._after_pack(self._pack[1])
+            self._pack_sig = sig
         return self._pack[1]
 
     def _after_pack(self, ptrs):

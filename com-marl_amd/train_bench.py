@@ -6,7 +6,7 @@ import time
 import torch
 
 
-def train_loop_measurement(env, policy, cfg, spec, world, rank, dev, seed, epochs=2, kind="commdp"):
+def train_loop_measurement(env, policy, cfg, spec, world, rank, dev, seed, epochs=2, kind="commdp", batch_size=None):
     from . import nets
     from .algos import CentralizedMAPPO
     from .sampler import CentralizedMAOnPolicyVectorizedSampler
@@ -26,7 +26,7 @@ def train_loop_measurement(env, policy, cfg, spec, world, rank, dev, seed, epoch
                             optimization_mini_epochs=10, device=dev)
     smp = CentralizedMAOnPolicyVectorizedSampler(algo, _Shell(env, spec), n_envs=env.B)
     smp.start_worker()
-    bs = env.B * env.N * mpl                          # every env contributes at least one full path
+    bs = batch_size or env.B * env.N * mpl            # default: every env contributes at least one full path
     t_roll = t_upd = 0.0
     steps = env_steps = 0
     stats = {}
@@ -56,6 +56,7 @@ def train_loop_measurement(env, policy, cfg, spec, world, rank, dev, seed, epoch
     return dict(value=world * env_steps / total, unit="env-steps/s", epochs=epochs,
                 rollout_s_per_epoch=t_roll / epochs, update_s_per_epoch=t_upd / epochs,
                 env_steps_per_epoch_per_gpu=env_steps // epochs, paths_per_epoch=stats.get("NumTrajs", 0) // env.N,
+                envs_per_gpu=env.B, batch_size_agent_steps=bs,
                 schedule="3 minibatches x 10 mini-epochs, Adam lr 3e-4, clip 0.1, grad all-reduce per step" if world > 1
                 else "3 minibatches x 10 mini-epochs, Adam lr 3e-4, clip 0.1",
                 loss_before=stats.get("LossBefore"), loss_after=stats.get("LossAfter"), kl=stats.get("KL"))

@@ -187,7 +187,12 @@ typedef struct cm_critic_weights {
  * wave fetches 1 KB per instruction, unconditionally, instead of 4 predicated dword gathers per fragment.
  * cm_*_pack_bytes: size of the pack for this net, 0 when the shape has no matrix-core instantiation (then leave
  * mfma_pack NULL).  cm_*_pack: (re)build it on `stream` from the plain [in,out] weights in *w - call after every
- * weight update; the buffer is caller-owned and may be rewritten in place (captured hipGraphs keep working). */
+ * weight update; the buffer is caller-owned and may be rewritten in place (captured hipGraphs keep working).
+ * The default kernels carry every weight as an (hi, lo) pair of f16 values: a weight with |w| > 65504, inf or NaN cannot
+ * be carried, and cm_*_pack REFUSE such a net (CM_ERR_ARG, text in cm_last_error()) instead of packing +-inf planes.  The
+ * check costs one 4-byte copy and a wait for the pack kernels on `stream`; it is skipped while `stream` is being captured
+ * (a capture cannot wait) and with COMMARL_PACK_CHECK=0.  Observations are expected in the envs' range ([-1, 1]); a
+ * foreign caller's |obs| > 65504 saturates the same way and is NOT checked per step. */
 size_t cm_policy_pack_bytes(const cm_policy_weights *w);
 int cm_policy_pack(const cm_policy_weights *w, float *pack, void *stream);
 size_t cm_critic_pack_bytes(const cm_critic_weights *w);

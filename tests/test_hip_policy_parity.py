@@ -428,3 +428,28 @@ def test_evaluate_nograd_shares_one_forward(torch_cuda):
         assert torch.equal(probs.reshape(P * T, n_agents, 5), ref)
         assert logits is not None and logits.shape == (P, T, n_agents, 5)
         np.testing.assert_allclose(torch.softmax(logits, -1).cpu().numpy(), probs.cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_weight_pack_refuses_weights_outside_the_f16_range():
+    """cm_policy_pack / cm_critic_pack: a weight the (hi, lo) f16 pair cannot carry (|w| > 65504, inf, NaN) is refused with a
+    status < 0 and a message, not packed as +-inf; the same net packs again once the weight is back in range."""
+    import torch
+    from com_marl_amd import _lib as L, envs as E, nets
+    spec = E.EnvSpec(E._Box(np.zeros(84), np.ones(84)), E._Discrete(5))
+    torch.manual_seed(0)
+    for net in (nets.CommCategoricalMLPPolicy(spec, n_agents=4, device="cuda:0"), nets.CommBaseCritic(spec, n_agents=4, device="cuda:0")):
+        net.sync_weights()                                            # fine as initialised
+        w = net.gcn_layers[1].weight
+        keep = w.detach().clone()
+        for bad in (7.0e4, -1.0e5, float("inf"), float("nan")):
+            with torch.no_grad():
+                w[3, 5] = bad
+            with pytest.raises(L.CommarlError, match="outside the f16 range"):
+                net.sync_weights()
+        with torch.no_grad():
+            w.copy_(keep)
+            w[3, 5] = 65504.0                                         # the largest f16 itself is fine
+        net.sync_weights()
+        with torch.no_grad():
+            w.copy_(keep)
+        net.sync_weights()
