@@ -175,10 +175,14 @@ def measure_rollout(config, args, rank, world, dev, steps, warmup, envs=None, st
     # first inside every chunk graph and the two stay out of phase; a timed region of a few ms cannot amortise that
     # start-up stagger (--steps 20 at config 2: 42 us/step as one shard, 45 as two; profiles/r02_steps_sweep.txt), so
     # short runs use one shard.
+    # teams of 4 on the wave-owned kernel run a whole chunk as ONE persistent launch (256 workgroups = one wave per SIMD at 4096
+    # envs): nothing is left for a second shard to overlap with, so they run as one shard.
+    persistent_w = (args.policy == "commdp" and c["n_agents"] == 4 and os.environ.get("COMMARL_PERSISTENT", "1") != "0"
+                    and os.environ.get("COMMARL_POLICY_KERNEL", "w")[:1] not in ("h", "f", "v"))
     if streams is not None:
         n_streams = streams
     else:
-        n_streams = 1 if steps * c["step_us"] < 10_000 else c.get("streams", 2)
+        n_streams = 1 if (persistent_w or steps * c["step_us"] < 10_000) else c.get("streams", 2)
     ns = n_streams if (n_streams > 1 and B % n_streams == 0) else 1
     if ns > 1:      # the same B envs (same global ids, same Philox streams) as `ns` shards, each on its own stream
         shards = [E.GridEnvBatch(c["scenario"], env_params(c), B // ns, device=dev, seed=args.seed,
@@ -190,7 +194,7 @@ def measure_rollout(config, args, rank, world, dev, steps, warmup, envs=None, st
     policy = make_policy(args.policy, spec, env.N, dev)
     policy.set_rng(args.seed, env_id_offset=rank * B)
     G = max(1, min(args.chunk, steps))             # steps per captured hipGraph
-    eng = RolloutEngine(shards, policy, horizon=G, persistent=os.environ.get("COMMARL_PERSISTENT", "0") == "1")
+    eng = RolloutEngine(shards, policy, horizon=G)        # persistent="auto": one launch per chunk where the wave-owned kernel applies
     eng.reset()
     use_graph = not args.no_graph
 
@@ -279,6 +283,12 @@ def measure_rollout(config, args, rank, world, dev, steps, warmup, envs=None, st
                 env, eng.obs[0].view(B, -1), adj0, ch0, so, out_actions=eng.actions[0], out_probs=eng.probs[0],
                 out_attn=None if eng.attn is None else eng.attn[0], policy_step=0, step_base=eng.step_base,
                 env_id_offset=rank * B))
+    # the timed region's launch when the engine runs chunks persistently: ONE cm_rollout_chunk launch = G steps of the whole batch
+    t_chunk = None
+    if eng._persistent and len(eng.parts) == 1:
+        eng.reset()
+        if eng.steps_fused(0, G):
+            t_chunk = time_kernel(lambda: eng.steps_fused(0, G), reps=5, inner=4)      # seconds per launch of G steps
     env.check_status()
     b_env, b_pol = algorithmic_bytes(c, env.d, env.adj_const, env.ch_const)
     flops = (policy_flops(c, env.d) if args.policy == "commdp" else variant_flops(c, env.d, args.policy)) * B
@@ -310,8 +320,12 @@ def measure_rollout(config, args, rank, world, dev, steps, warmup, envs=None, st
     kernels = {kname: kernel_row("mfma", t_pol, flops, b_pol * B), "cm_env_step": kernel_row("hbm", t_env, 0, b_env * B)}
     if t_fused is not None:
         kernels["cm_rollout_step"] = kernel_row("mfma", t_fused, flops, (b_env + b_pol) * B)
-    # the dominant kernel of the TIMED REGION: the fused rollout step when the chunks were captured with it
-    dom = "cm_rollout_step" if t_fused is not None else (kname if t_pol >= t_env else "cm_env_step")
+    if t_chunk is not None:      # per launch: G steps of the whole batch; `us` is the launch, `us_per_step` what one step costs inside it
+        kernels["cm_rollout_chunk"] = kernel_row("mfma", t_chunk, flops * G, (b_env + b_pol) * B * G)
+        kernels["cm_rollout_chunk"].update(steps_per_launch=G, us_per_step=t_chunk / G * 1e6)
+    # the dominant kernel of the TIMED REGION: the persistent chunk, else the fused rollout step when the chunks were captured with it
+    dom = "cm_rollout_chunk" if t_chunk is not None else (
+        "cm_rollout_step" if t_fused is not None else (kname if t_pol >= t_env else "cm_env_step"))
     tr = (traffic or {}).get(dom) if isinstance(traffic, dict) else None
     roofline = dict(kernel=dom, **{k: kernels[dom][k] for k in ("bound", "achieved", "peak", "unit", "frac", "hbm_frac")},
                     traffic=tr,
@@ -420,7 +434,9 @@ def main():
                                + "; one step = fused policy forward + sample + env step with auto-reset, "
                                "trajectory written to HBM", "envs_per_gpu": B, "total_envs": B * world, "n_agents": c["n_agents"],
                    "obs_dim": env.d, "graph_chunk": 0 if args.no_graph else G, "streams": ns,
-                   "step_launches": ("1 (cm_rollout_step: policy forward + sample + env step fused)" if eng._fused_in_graph
+                   "step_launches": (f"1 per chunk of {G} steps (cm_rollout_chunk: a wave keeps its envs and the weights for the whole chunk)"
+                                     if eng._persistent and eng._fused else
+                                     "1 (cm_rollout_step: policy forward + sample + env step fused)" if eng._fused_in_graph
                                      and eng._fused else "2 (cm_policy_forward, cm_env_step)"),
                    "graphs": {"count": n_captured, "chunk_lengths": timed_lengths if use_graph else [],
                               "capture_in_timed_region": False,

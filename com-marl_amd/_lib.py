@@ -206,13 +206,13 @@ def destroy_env(handle):
 
 
 class capture_guard:
-    """``with capture_guard(): <stream capture>``: collects garbage BEFORE the capture opens, keeps the cyclic collector off
-    while it is open, and defers every env-handle destruction requested meanwhile to the exit."""
+    """``with capture_guard(): <stream capture>``: keeps the cyclic collector off while the capture is open and defers every
+    env-handle destruction requested meanwhile (a refcount reaching zero) to the exit.  (No gc.collect() here: a full
+    collection costs ~50 ms in a process that has torch loaded, and a sampler captures dozens of span graphs.)"""
 
     def __enter__(self):
         global _capture_depth
         import gc
-        gc.collect()
         self._gc_was_on = gc.isenabled()
         gc.disable()
         _capture_depth += 1

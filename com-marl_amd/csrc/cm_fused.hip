@@ -17,6 +17,13 @@
 
 namespace cm {
 
+// cm_rollout_w.hip: teams of 4 on wave-owned rows (single step, or a persistent chunk); 1 = not available for this handle
+int launch_rollout_w(mf::FwdArgs a, const cm_policy_weights *w, const void *w_pack, const cm_env *h, const cm_rng_tape &t, const cm_step_out &out,
+                     void *stream, const ChunkArgs *chunk);
+bool shape_ok_rollout_w(int N, int d, int L, int n_act);
+
+bool policy_w_enabled();                                 // cm_policy_w.hip: wave-owned teams-of-4 kernel (default where the shape allows)
+size_t policy_pack_h_bytes(int d, int L, bool policy);   // cm_policy_h.hip: size of the f16 pack the wave-owned fragments sit behind
 bool policy_h_enabled();                                 // cm_policy_h.hip: f16-split dense layers (default) or the all-f32 body
 
 // POL selects the policy body: 0 = cm_policy_mfma_dev.h (all f32), 1 = cm_policy_h_dev.h (f16-split dense layers).  Both
@@ -63,11 +70,6 @@ __global__ __launch_bounds__(mf::TPB) void rollout_step_kernel(mf::FwdArgs a, mf
 // and one launch per chunk: a step costs the workgroup's own policy + env chain (28.6 us at the headline config), without
 // the grid drain of a launch per step.  Step t+1 reads what step t wrote (observation, masks, env state) through the
 // CU's own write-through L1 / L2: a workgroup-scope release / acquire pair around the workgroup barrier orders them.
-struct ChunkArgs {
-    int n_steps;
-    int stagger;              // late start of the second half of the grid, in units of s_sleep 32 (~2048 clocks)
-    long long obs, actions, probs, attn, reward, reward_f64, done, details, dist_adj, channels, prey_alive, success, path_len;
-};
 
 // Two waves per SIMD as the single-step kernel: without the bound the compiler hoists every layer's (step-invariant) weight
 // fragment loads out of the step loop, ends at 506 VGPRs and one workgroup per CU - half the grid waits for the other
@@ -231,6 +233,10 @@ static int rollout_impl(cm_env_t h, const cm_policy_weights *w, const float *obs
     // instantiations: the four BASELINE shapes (PP sen1 small teams; CO sen2 mid teams; PP / CO sen2 large teams)
     const bool quad = d.N == 4 && mf::pick_epb(4) * 4 <= 32;
     const int kh = mh::kh_of(d.d);
+    if (policy_w_enabled() && shape_ok_rollout_w(d.N, d.d, d.L, w->n_act)) {    // teams of 4: wave-owned rows, single step or persistent chunk
+        const int rc = launch_rollout_w(a, w, reinterpret_cast<const char *>(P + lo.total) + policy_pack_h_bytes(d.d, d.L, true), h, t, *out, stream, chunk);
+        if (rc != 1) return rc;
+    }
     if (policy_h_enabled() && kh) {                  // f16-split dense layers: the operand pack behind the f32 one
         const mh::PackLayoutH lh = mh::pack_layout_h(kh, d.L, true);
         const uint4 *Q = reinterpret_cast<const uint4 *>(P + lo.total);

@@ -94,6 +94,14 @@ struct cm_env {
 };
 
 namespace cm {
+// Per-step element strides of the time-major trajectory buffers, for the kernels that run several rollout steps per launch
+// (cm_rollout_chunk): step t reads / writes base + t * stride.
+struct ChunkArgs {
+    int n_steps;
+    int stagger;              // late start of the second half of the grid, in units of s_sleep 32 (~2048 clocks)
+    long long obs, actions, probs, attn, reward, reward_f64, done, details, dist_adj, channels, prey_alive, success, path_len;
+};
+
 int check_tape(const cm_env *h, const cm_rng_tape *tape, bool is_reset);   // cm_env.hip: tape pointers the config needs
 namespace mf {
 // cm_policy_mfma.hip: one layer's weights [K,OUT] -> MFMA B fragments [out_pad/16][kpad/16][64 lanes][4], zero padded

@@ -185,6 +185,8 @@ bool policy_h_enabled() {
     return v;
 }
 
+int policy_pack_w(const cm_policy_weights *w, void *dst, void *stream, int *bad);   // cm_policy_w.hip
+
 size_t policy_pack_h_bytes(int d, int L, bool policy) {
     const int kh = mh::kh_of(d);
     return kh ? mh::pack_layout_h(kh, L, policy).total * sizeof(uint4) : 0;
@@ -201,6 +203,8 @@ int policy_pack_h(const cm_policy_weights *w, void *dst, void *stream) {
     if (int rc = mh::pack_one_h(w->hd_w2t, mf::H1, mf::H2, mf::H1, mf::H2, pack + lo.h2, stream, bad)) return rc;
     if (int rc = mh::pack_one_h(w->hd_w3t, mf::H2, mf::H3, mf::H2, mf::H3, pack + lo.h3, stream, bad)) return rc;
     if (int rc = mh::pack_one_h(w->hd_w4t, mf::H3, w->n_act, mf::H3, 16, pack + lo.h4, stream, bad)) return rc;
+    // teams of 4: the wave-owned kernel's fragments (another k order, cm_policy_w.hip), behind this section
+    if (int rc = policy_pack_w(w, reinterpret_cast<char *>(dst) + lo.total * sizeof(uint4), stream, bad)) return rc;
     return mh::range_check_end(bad, stream, "cm_policy_pack");
 }
 

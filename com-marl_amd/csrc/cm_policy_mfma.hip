@@ -149,6 +149,9 @@ size_t policy_pack_h_bytes(int d, int L, bool policy);
 int policy_pack_h(const cm_policy_weights *w, void *dst, void *stream);
 int critic_pack_h(const cm_critic_weights *w, void *dst, void *stream);
 int policy_forward_h(const cm_policy_weights *w, const void *h_pack, mf::FwdArgs a, void *stream);
+// cm_policy_w.hip: the wave-owned teams-of-4 kernel (default where the shape allows); its fragments sit behind the f16 pack
+size_t policy_pack_w_bytes(const cm_policy_weights *w);
+int policy_forward_w(const cm_policy_weights *w, const void *w_pack, mf::FwdArgs a, void *stream);
 int critic_forward_h(const cm_critic_weights *w, const void *h_pack, mf::FwdArgs a, void *stream);
 
 bool policy_shape_ok(const cm_policy_weights *w) {
@@ -177,6 +180,10 @@ int policy_forward_mfma(const cm_policy_weights *w, int32_t S, const float *obs,
     { const char *e = getenv("COMMARL_FWD_STOP"); a.stop = e ? atoi(e) : 0; }
     const mf::PackLayout lo = mf::pack_layout(mf::kpad_of(w->d), w->n_hops, true);
     const float *P = w->mfma_pack;
+    if (policy_pack_w_bytes(w)) {
+        const int rc = policy_forward_w(w, reinterpret_cast<const char *>(P + lo.total) + policy_pack_h_bytes(w->d, w->n_hops, true), a, stream);
+        if (rc <= 0) return rc;
+    }
     if (policy_h_enabled()) {
         const int rc = policy_forward_h(w, P + lo.total, a, stream);
         if (rc <= 0) return rc;
@@ -243,7 +250,8 @@ extern "C" int cm_critic_forward_saved(const cm_critic_weights *w, int32_t S, co
 
 extern "C" size_t cm_policy_pack_bytes(const cm_policy_weights *w) {
     if (!cm::policy_shape_ok(w)) return 0;
-    return cm::mf::pack_layout(cm::mf::kpad_of(w->d), w->n_hops, true).total * sizeof(float) + cm::policy_pack_h_bytes(w->d, w->n_hops, true);
+    return cm::mf::pack_layout(cm::mf::kpad_of(w->d), w->n_hops, true).total * sizeof(float) + cm::policy_pack_h_bytes(w->d, w->n_hops, true) +
+           cm::policy_pack_w_bytes(w);
 }
 
 extern "C" int cm_policy_pack(const cm_policy_weights *w, float *pack, void *stream) {

@@ -1,0 +1,107 @@
+// cm_rollout_w.hip - the rollout step of teams of 4 on WAVE-OWNED rows: Comm-DP policy forward + sample (cm_policy_w_dev.h) and
+// the env step (cm_env_dev.h) of a wave's four envs, by that wave alone, for one step or a whole chunk of steps per launch
+// (reference: centralized_ma_on_policy_vectorized_sampler.py:119-232 - get_actions, vec_env.step, obses = next_obses).
+// Its own translation unit: built with -fno-slp-vectorize (Makefile), which the older kernels of cm_fused.hip are not.
+#include <stdlib.h>
+
+#include "cm_env_dev.h"
+#include "cm_policy_w_dev.h"
+
+namespace cm {
+
+bool policy_w_enabled();                                 // cm_policy_w.hip
+
+// ---- teams of 4, wave-owned rows (cm_policy_w_dev.h): a workgroup = 16 envs = four waves, ONE per SIMD; a wave carries its four
+// envs through policy forward, sample AND env step by itself - the actions go through LDS words only that wave touches, the env
+// phase's 16-lane groups are the wave's own envs - so no workgroup barrier exists after the one behind the weight staging, and
+// with n_steps > 1 the wave simply loops (weights stay where they are: LDS image + the register-resident 128 -> 64 layer).
+// LDS: [policy image | 64 actions | 16 env areas].
+template <int LHOPS, bool PRE, bool FULLWG>
+__global__ __launch_bounds__(256) void rollout_w_kernel(mf::FwdArgs a, mw::WeightsW w, EnvDev p, cm_rng_tape tape, cm_step_out out, ChunkArgs c) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_w[];
+    constexpr int LPE = 16;
+    constexpr int ACT_OFF = mw::pack_w(LHOPS).lds_u4 * 16, ENV_BASE = ACT_OFF + mw::WG_ROWS * 4;
+    int32_t *act = reinterpret_cast<int32_t *>(lds_w + ACT_OFF);
+    mw::ResidentW res;
+    res.fetch<LHOPS>(w, thread_x() & 63);
+    mw::stage_w<LHOPS>(w, lds_w, thread_x());
+    __syncthreads();                                                     // the only workgroup barrier of the launch
+    const int envs = FULLWG ? mw::WG_ENVS : min(mw::WG_ENVS, a.S - (int)blockIdx.x * mw::WG_ENVS);
+    for (int t = 0; t < c.n_steps; ++t) {
+        asm volatile("" ::: "memory");                                   // keep each step's loads inside the step
+        const int tx = thread_x(), grp = tx / LPE;
+        const bool live = FULLWG || grp < envs;
+        const bool env_wave = FULLWG || (tx & ~63) / LPE < envs;        // a wave with an env of its own
+        const int b_raw = blockIdx.x * mw::WG_ENVS + (live ? grp : 0);
+        mf::FwdArgs at = a;
+        at.obs = a.obs + t * c.obs;
+        at.adj = a.adj ? a.adj + t * c.dist_adj : nullptr;
+        at.chan = a.chan ? a.chan + t * c.channels : nullptr;
+        at.policy_step = a.policy_step + (uint32_t)t;
+        at.actions = a.actions ? a.actions + t * c.actions : nullptr;
+        at.probs = a.probs ? a.probs + t * c.probs : nullptr;
+        at.attn = a.attn ? a.attn + t * c.attn : nullptr;
+        EnvPre pre{};
+        if constexpr (PRE) pre = env_prefetch<CM_PP, LPE>(p, b_raw, live);   // env state requested in front of the policy forward
+        mw::policy_tile_w<LHOPS>(at, w.n_act, res, lds_w, blockIdx.x, act);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // this wave's action words are in LDS
+        cm_step_out ot = out;
+        if (ot.obs) ot.obs += t * c.obs;
+        if (ot.reward) ot.reward += t * c.reward;
+        if (ot.reward_f64) ot.reward_f64 += t * c.reward_f64;
+        if (ot.done) ot.done += t * c.done;
+        if (ot.details) ot.details += t * c.details;
+        if (ot.dist_adj) ot.dist_adj += t * c.dist_adj;
+        if (ot.channels) ot.channels += t * c.channels;
+        if (ot.prey_alive) ot.prey_alive += t * c.prey_alive;
+        if (ot.success) ot.success += t * c.success;
+        if (ot.path_len) ot.path_len += t * c.path_len;
+        if (env_wave) {
+            const int32_t *my_act = act + (live ? grp : 0) * 4;
+            if constexpr (PRE) {
+                const bool bad = env_stage<CM_PP, LPE>(p, pre, my_act, grp, ENV_BASE);
+                env_body<CM_PP, LPE>(p, nullptr, my_act, tape, ot, 0, grp, b_raw, live, ENV_BASE, nullptr, true, pre.rng_step, pre.step_count_in,
+                                     pre.succ, pre.t_row, pre.t_col, pre.t_step0, pre.t_step, pre.t_rew, bad, FULLWG);
+            } else env_body<CM_PP, LPE>(p, nullptr, my_act, tape, ot, 0, grp, b_raw, live, ENV_BASE);
+        }
+        // step t + 1 reads what this WAVE wrote (observation, masks, env state): its stores are performed before its next loads;
+        // the CU's vector L1 is write-through and shared, so workgroup scope needs no cache maintenance (as rollout_chunk_kernel)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+}
+
+bool shape_ok_rollout_w(int N, int d, int L, int n_act) { return policy_w_enabled() && mw::shape_ok_w(N, d, L, n_act); }
+
+// Launch of the wave-owned rollout kernel; 1 = not available for this shape / handle.
+int launch_rollout_w(mf::FwdArgs a, const cm_policy_weights *w, const void *w_pack, const cm_env *h, const cm_rng_tape &t, const cm_step_out &out,
+                    void *stream, const ChunkArgs *chunk) {
+    const EnvDev &d = h->dev;
+    if (d.scen != CM_PP || d.lpe != 16 || d.M > 16 || d.N != 4) return 1;
+    const size_t lds = mw::lds_policy_bytes(d.L) + (size_t)d.lds_env * mw::WG_ENVS;
+    if (lds > 160 * 1024) return 1;                                      // larger maps: the env areas do not fit beside the weights
+    const mw::WeightsW ww{ reinterpret_cast<const uint4 *>(w_pack), w->n_act };
+    ChunkArgs c{};
+    c.n_steps = 1;
+    if (chunk) c = *chunk;
+    const int blocks = (a.S + mw::WG_ENVS - 1) / mw::WG_ENVS;
+    static const int pre_flag = [] { const char *e = getenv("COMMARL_ENV_PREFETCH"); return (e && e[0] == '0') ? 0 : 1; }();
+    const bool pre = pre_flag && env_prefetch_ok<CM_PP, 16>(d), full = a.S % mw::WG_ENVS == 0;
+#define CM_RW(LH, PR, FU)                                                                                                       \
+    do {                                                                                                                        \
+        static unsigned long long done = 0;                                                                                     \
+        if (cm::dev_first(done))                                                                                                \
+            CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_w_kernel<LH, PR, FU>),                           \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                                \
+        hipLaunchKernelGGL((rollout_w_kernel<LH, PR, FU>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, a, ww, d, t, out, c); \
+    } while (0)
+#define CM_RW2(LH) do { if (pre) { if (full) CM_RW(LH, true, true); else CM_RW(LH, true, false); }                              \
+                        else { if (full) CM_RW(LH, false, true); else CM_RW(LH, false, false); } } while (0)
+    if (d.L == 1) CM_RW2(1); else CM_RW2(2);
+#undef CM_RW2
+#undef CM_RW
+    CM_HIP(hipGetLastError());
+    return CM_OK;
+}
+
+}  // namespace cm

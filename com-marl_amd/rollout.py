@@ -46,7 +46,7 @@ class _Parts:
 
 
 class RolloutEngine:
-    def __init__(self, env, policy, horizon, store_attn=True, store_probs=True, fused="auto", persistent=False,
+    def __init__(self, env, policy, horizon, store_attn=True, store_probs=True, fused="auto", persistent="auto",
                  graph_fused=True):
         """env: envs.GridEnvBatch, or a list of shards of one batch (then every shard runs its own
         policy -> env chain on its own HIP stream: the chains are independent, so kernels of different
@@ -83,17 +83,22 @@ class RolloutEngine:
         # copy on its own stream (all copies always hold the same value), so that the shards' chains share nothing
         self.step_bases = [torch.zeros(1, dtype=i32, device=dev) for _ in self.parts]
         self._graphs = {}
-        # fused: eager step() calls use cm_rollout_step (one launch instead of two: the host-bound sampler / eval loops
-        # gain; captured chunks keep the two-kernel form, which replays ~2 % faster because the env kernels of one
-        # shard fill the tail of the other's policy kernel).  persistent: run_chunk as ONE cm_rollout_chunk launch per
-        # shard - bit-identical, but measured slower on MI355X (the drifting workgroups thrash the instruction cache:
-        # 52 us vs 36 us per step at the headline config), so it is opt-in.
-        # fused="auto": the one-launch step only for teams of 4, where it wins (config 2: 27.1 vs 28.5 us per step);
-        # for larger teams the fused kernel runs the env step of ONE env on a 256-thread workgroup that is mostly idle
-        # (measured per step: N = 24 127 vs 95 us, N = 72 424 vs 176 us), so they take the two-kernel form.  True forces
-        # it (parity tests), False disables it.
+        # fused: step() uses cm_rollout_step (policy forward + sample + env step in one launch) where the library has a fused
+        # kernel for the shape.  fused="auto": teams of 4 only - for larger teams the fused kernel runs the env step of ONE env on
+        # a 256-thread workgroup that is mostly idle (measured per step: N = 24 127 vs 95 us, N = 72 424 vs 176 us), so they take
+        # the two-kernel form.  True forces it (parity tests), False disables it.
+        # persistent: a chunk / span of steps as ONE cm_rollout_chunk launch per shard.  "auto": teams of 4 on the wave-owned
+        # kernel (csrc/cm_rollout_w.hip: a wave keeps its four envs and the weights stay in LDS / registers for the whole
+        # chunk - 17.0 us per step at the headline config against 24.7 for one launch per step, which re-stages 145 KB of
+        # weights per workgroup every step); the older workgroup-tiled kernels (COMMARL_POLICY_KERNEL=h / f32) step faster
+        # with one launch per step under a hipGraph and keep that form.  Both forms are bit-identical
+        # (tests/test_hip_fused_parity.py).
         if fused == "auto":
             fused = getattr(policy, "_n_agents", 0) == 4
+        if persistent == "auto":
+            pk = os.environ.get("COMMARL_POLICY_KERNEL", "w")[:1]
+            persistent = bool(fused) and getattr(policy, "_n_agents", 0) == 4 and pk not in ("h", "f", "v") \
+                and os.environ.get("COMMARL_PERSISTENT", "1") != "0"
         self._fused = None if fused else False              # None = try the fused step, False = two launches per step
         self._persistent = bool(persistent and fused)
         self._capturing = False
@@ -264,6 +269,14 @@ class RolloutEngine:
                         self._chunk_tail(k, t0 + n)
                 self.join()
             return
+        if self._persistent and self.steps_fused(t0, n):    # one launch per shard for the whole span
+            if tail:
+                self.fork()
+                for k, st in enumerate(self.streams):
+                    with torch.cuda.stream(st) if st is not None else _null():
+                        self._chunk_tail(k, t0 + n)
+                self.join()
+            return
         self.fork()
         for t in range(t0, t0 + n):
             for k, st in enumerate(self.streams):
@@ -338,14 +351,9 @@ class RolloutEngine:
         (tests/test_hip_ppo_parity.py)."""
         n = self.H if n is None else int(n)
         assert 1 <= n <= self.H
-        if self._persistent and self.steps_fused(0, n):
-            self.fork()
-            for k, st in enumerate(self.streams):
-                with torch.cuda.stream(st) if st is not None else _null():
-                    self._chunk_tail(k, n)                  # slot n -> slot 0 and the Philox base, one launch per shard
-            self.join()
-            return
         if not use_graph:
+            if not weights_synced:
+                self.policy.sync_weights()
             self._chunk(n)
             return
         g = self._graphs.get((0, n, True)) or self.prepare_graph(n)
@@ -358,6 +366,8 @@ class RolloutEngine:
         strings together.  One hipGraph per (t0, n), captured on first use and reused by every later rollout of this
         engine (the trajectory slots, the weight pack and the Philox base are fixed device addresses)."""
         if not use_graph:
+            if not weights_synced:
+                self.policy.sync_weights()
             self._chunk(n, t0, tail=False)
             return
         g = self._graphs.get((t0, n, False)) or self.prepare_graph(n, t0, tail=False)

@@ -327,6 +327,12 @@ class CentralizedMAOnPolicyVectorizedSampler:
         eng.reset()
         policy.reset([True] * B)
         pol_share = self._kernel_split(eng)
+        if use_graph and not getattr(eng, "_spans_ready", False):
+            # every span graph of the horizon once, up front: a later rollout that runs one span longer must not pay a
+            # capture (capturing executes nothing: the rollout below starts from the state the reset left)
+            for t0 in range(0, eng.H, chunk):
+                eng.prepare_graph(min(chunk, eng.H - t0), t0, tail=False)
+            eng._spans_ready = True
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
         t, stop_t = 0, None

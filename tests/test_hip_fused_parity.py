@@ -111,14 +111,14 @@ def test_run_chunk_uses_the_persistent_kernel_and_matches_stepwise_launches():
     from com_marl_amd.rollout import RolloutEngine
     scen, map_, sen, N, M, load, loss, B, steps, mpl = SHAPES["pp_map10"]
     outs = []
-    for persistent, use_graph in ((True, False), (False, False), (False, True)):
+    for persistent, use_graph in ((True, False), (False, False), (False, True), (True, True), ("auto", True)):
         shards = [E.GridEnvBatch(scen, _params(scen, map_, sen, N, M, load, loss, mpl), 64, device="cuda:0", seed=3,
                                  max_steps=mpl, max_path_length=mpl, env_id_offset=64 * k) for k in range(2)]
         spec = E.EnvSpec(E._Box(np.zeros(shards[0].d * N), np.ones(shards[0].d * N)), E._Discrete(5))
         torch.manual_seed(3)
         pol = nets.CommCategoricalMLPPolicy(spec, n_agents=N, device="cuda:0")
         pol.set_rng(3)
-        eng = RolloutEngine(shards, pol, 12, persistent=persistent)   # persistent is opt-in
+        eng = RolloutEngine(shards, pol, 12, persistent=persistent)   # default "auto": persistent for teams of 4
         eng.reset()
         for _ in range(3):
             eng.run_chunk(use_graph=use_graph)  # graph capture does not advance the rollout: comparable slot by slot

@@ -408,8 +408,10 @@ def test_fused_training_path_vs_per_layer_autograd(d, hops, residual, masks, N, 
 
 def test_evaluate_nograd_shares_one_forward(torch_cuda):
     """policy.evaluate_nograd (ONE launch giving logits and action probabilities: what train_once shares between the
-    loss, the old log-likelihood and the KL / entropy diagnostics) returns the probabilities of act_device bit for bit
-    and logits whose softmax they are, for teams of 4 (register path) and other sizes alike."""
+    loss, the old log-likelihood and the KL / entropy diagnostics) returns the probabilities of act_device and logits whose
+    softmax they are.  Bit for bit where act_device runs the same workgroup-tiled body (every team size but 4); teams of 4 act
+    through the wave-owned kernel (cm_policy_w_dev.h: same arithmetic scheme, another summation order), f32-grade agreement.
+    (train_once takes BOTH sides of its probability ratio from evaluate_nograd / the training forward, never from act_device.)"""
     torch = torch_cuda
     from com_marl_amd import nets
     from com_marl_amd.envs import EnvSpec, _Box, _Discrete
@@ -425,13 +427,17 @@ def test_evaluate_nograd_shares_one_forward(torch_cuda):
         _, ref, _ = pol.act_device(obs.reshape(P * T, -1), None, adj.reshape(P * T, n_agents, n_agents),
                                    ch.reshape(P * T, 2, n_agents, n_agents), want_actions=False, want_attn=False, policy_step=0)
         assert probs.shape == (P, T, n_agents, 5)
-        assert torch.equal(probs.reshape(P * T, n_agents, 5), ref)
+        if n_agents == 4 and os.environ.get("COMMARL_POLICY_KERNEL", "w")[:1] not in ("h", "f", "v"):
+            np.testing.assert_allclose(probs.reshape(P * T, n_agents, 5).cpu().numpy(), ref.cpu().numpy(), rtol=3e-6, atol=3e-7)
+        else:
+            assert torch.equal(probs.reshape(P * T, n_agents, 5), ref)
         assert logits is not None and logits.shape == (P, T, n_agents, 5)
         np.testing.assert_allclose(torch.softmax(logits, -1).cpu().numpy(), probs.cpu().numpy(), rtol=1e-5, atol=1e-6)
 
 
 def test_weight_pack_refuses_weights_outside_the_f16_range():
-    """cm_policy_pack / cm_critic_pack: a weight the (hi, lo) f16 pair cannot carry (|w| > 65504, inf, NaN) is refused with a
+    """cm_policy_pack / cm_critic_pack: a weight the (hi, lo) f16 pair cannot carry (|w| > 65504 - 22 700 where the wave-owned
+    pack folds the tanh prescale in -, inf, NaN) is refused with a
     status < 0 and a message, not packed as +-inf; the same net packs again once the weight is back in range."""
     import torch
     from com_marl_amd import _lib as L, envs as E, nets
@@ -448,7 +454,8 @@ def test_weight_pack_refuses_weights_outside_the_f16_range():
                 net.sync_weights()
         with torch.no_grad():
             w.copy_(keep)
-            w[3, 5] = 65504.0                                         # the largest f16 itself is fine
+            w[3, 5] = 2.0e4                                           # a large weight inside the range is fine (tanh layers carry
+                                                                      # 2 log2(e) w in the wave-owned pack: the limit there is 65504 / 2.885)
         net.sync_weights()
         with torch.no_grad():
             w.copy_(keep)
