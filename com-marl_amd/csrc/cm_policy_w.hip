@@ -15,7 +15,7 @@ namespace cm {
 namespace mw {
 
 template <int LHOPS>
-__global__ __launch_bounds__(256) void fwd_w_kernel(FwdArgs a, WeightsW w) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void fwd_w_kernel(FwdArgs a, WeightsW w) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_w[];
     fwd_body_w<LHOPS>(a, w, lds_w, blockIdx.x, nullptr);
 }

@@ -103,6 +103,9 @@ struct Frags {
                 h[ct][q] = __builtin_bit_cast(v8h, W[((ct * KB + q) * 2 + 0) * FRAG + lane]);
                 l[ct][q] = __builtin_bit_cast(v8h, W[((ct * KB + q) * 2 + 1) * FRAG + lane]);
             }
+        // left to itself the scheduler sinks every read to just in front of its MFMA (one exposed LDS round trip per tile and
+        // k block); the barrier keeps the whole batch of reads where it was written: ahead of the layer that runs meanwhile
+        __builtin_amdgcn_sched_barrier(0);
     }
 };
 
@@ -123,17 +126,23 @@ __device__ __forceinline__ void tanh_stage(float (&v)[N]) {
 #pragma unroll
     for (int i = 0; i < N; ++i) v[i] = fmaf(-2.0f, e[i], 1.0f);
 }
-// y -> (hi, lo) f16 planes:  hi = f16(y), lo = f16(4096 y - 4096 hi)  (both products and their difference are exact in f32; the
-// last line is one v_fma_mix*_f16)
+// y -> (hi, lo) f16 planes:  hi = f16(y), lo = f16((y - hi) 4096).  Pairs go through v_cvt_pk_f16_f32 (two values per
+// instruction); measured per value (tools/micro/wave_chain.hip, one wave per SIMD): 16 clk, against 24 for the form that ends in
+// v_fma_mix*_f16.
+typedef _Float16 v2h __attribute__((ext_vector_type(2)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 template <int N>
 __device__ __forceinline__ void split_stage(const float (&y)[N], h16 (&h)[N], h16 (&l)[N]) {
-    float t[N];
+    static_assert(N % 2 == 0, "pairs");
+    float d[N];
 #pragma unroll
-    for (int i = 0; i < N; ++i) h[i] = (h16)y[i];
+    for (int i = 0; i < N; i += 2) { const v2h p = __builtin_convertvector((v2f){ y[i], y[i + 1] }, v2h); h[i] = p[0]; h[i + 1] = p[1]; }
 #pragma unroll
-    for (int i = 0; i < N; ++i) t[i] = y[i] * LO_SCALE;
+    for (int i = 0; i < N; ++i) d[i] = y[i] - (float)h[i];
 #pragma unroll
-    for (int i = 0; i < N; ++i) l[i] = (h16)fmaf((float)h[i], -LO_SCALE, t[i]);
+    for (int i = 0; i < N; ++i) d[i] *= LO_SCALE;
+#pragma unroll
+    for (int i = 0; i < N; i += 2) { const v2h p = __builtin_convertvector((v2f){ d[i], d[i + 1] }, v2h); l[i] = p[0]; l[i + 1] = p[1]; }
 }
 
 // One dense layer on this wave's 16 rows, transposed form: a lane ends with features 16 ct + 4 g + r of row c.  Tiles are
@@ -215,15 +224,21 @@ template <int LHOPS>
 __device__ __forceinline__ void stage_w(const WeightsW &w, unsigned char *lds, int tid) {
     constexpr PackW pk = pack_w(LHOPS);
     uint4 *WL = reinterpret_cast<uint4 *>(lds);
-    constexpr int BATCH = 8, WHOLE = pk.lds_u4 / (256 * BATCH) * (256 * BATCH);
-    for (int base = 0; base < WHOLE; base += 256 * BATCH) {
+    // two rounds of ~18 chunks per thread, every load of a round in flight before its first store (at this point of the kernel
+    // the registers are free): two L2 round trips instead of five
+    constexpr int PER = (pk.lds_u4 + 255) / 256, BATCH = (PER + 1) / 2;
+    // every workgroup of the launch reads the SAME 145 KB at the same time: each starts at another 4 KB chunk, so that at any
+    // moment the CUs spread over the L2 channels instead of queueing on the same lines
+    const int rot = (int)((blockIdx.x * 7u) % (unsigned)(2 * BATCH));
+    auto chunk_of = [&](int j) { const int c = j + rot; return c >= 2 * BATCH ? c - 2 * BATCH : c; };
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
         uint4 v[BATCH];
 #pragma unroll
-        for (int k = 0; k < BATCH; ++k) v[k] = w.pack[base + k * 256 + tid];
+        for (int k = 0; k < BATCH; ++k) { const int i = chunk_of(round * BATCH + k) * 256 + tid; v[k] = w.pack[i < pk.lds_u4 ? i : 0]; }
 #pragma unroll
-        for (int k = 0; k < BATCH; ++k) WL[base + k * 256 + tid] = v[k];
+        for (int k = 0; k < BATCH; ++k) { const int i = chunk_of(round * BATCH + k) * 256 + tid; if (i < pk.lds_u4) WL[i] = v[k]; }
     }
-    for (int i = WHOLE + tid; i < pk.lds_u4; i += 256) WL[i] = w.pack[i];
 }
 
 // the register-resident layer (128 -> 64 of the head): fetched once per wave, from the pack in global memory
@@ -437,9 +452,9 @@ template <int LHOPS>
 __device__ __forceinline__ void fwd_body_w(const FwdArgs &a, const WeightsW &w, unsigned char *lds, int blk, int32_t *act_lds) {
     const int tid = thread_x();
     CM_WPROBE(0);
+    stage_w<LHOPS>(w, lds, tid);
     ResidentW res;
     res.fetch<LHOPS>(w, tid & 63);
-    stage_w<LHOPS>(w, lds, tid);
     CM_WPROBE(1);
     __syncthreads();
     policy_tile_w<LHOPS>(a, w.n_act, res, lds, blk, act_lds);

@@ -2,6 +2,7 @@
 // the env step (cm_env_dev.h) of a wave's four envs, by that wave alone, for one step or a whole chunk of steps per launch
 // (reference: centralized_ma_on_policy_vectorized_sampler.py:119-232 - get_actions, vec_env.step, obses = next_obses).
 // Its own translation unit: built with -fno-slp-vectorize (Makefile), which the older kernels of cm_fused.hip are not.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "cm_env_dev.h"
@@ -11,21 +12,28 @@ namespace cm {
 
 bool policy_w_enabled();                                 // cm_policy_w.hip
 
+// diagnostic (COMMARL_ENV_STOP=-2): shader clocks of workgroup 0 / thread 0, summed over the launch's steps: [0] steps, [1] policy
+// tile, [2] env phase, [3] weight staging
+static __device__ unsigned long long g_w_probe[4];
+
 // ---- teams of 4, wave-owned rows (cm_policy_w_dev.h): a workgroup = 16 envs = four waves, ONE per SIMD; a wave carries its four
 // envs through policy forward, sample AND env step by itself - the actions go through LDS words only that wave touches, the env
 // phase's 16-lane groups are the wave's own envs - so no workgroup barrier exists after the one behind the weight staging, and
 // with n_steps > 1 the wave simply loops (weights stay where they are: LDS image + the register-resident 128 -> 64 layer).
 // LDS: [policy image | 64 actions | 16 env areas].
 template <int LHOPS, bool PRE, bool FULLWG>
-__global__ __launch_bounds__(256) void rollout_w_kernel(mf::FwdArgs a, mw::WeightsW w, EnvDev p, cm_rng_tape tape, cm_step_out out, ChunkArgs c) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rollout_w_kernel(mf::FwdArgs a, mw::WeightsW w, EnvDev p, cm_rng_tape tape, cm_step_out out, ChunkArgs c) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_w[];
     constexpr int LPE = 16;
     constexpr int ACT_OFF = mw::pack_w(LHOPS).lds_u4 * 16, ENV_BASE = ACT_OFF + mw::WG_ROWS * 4;
     int32_t *act = reinterpret_cast<int32_t *>(lds_w + ACT_OFF);
+    const bool probe = p.stop == -2 && blockIdx.x == 0 && thread_x() == 0;
+    const unsigned long long t_in = probe ? __builtin_amdgcn_s_memtime() : 0ull;
+    mw::stage_w<LHOPS>(w, lds_w, thread_x());
     mw::ResidentW res;
     res.fetch<LHOPS>(w, thread_x() & 63);
-    mw::stage_w<LHOPS>(w, lds_w, thread_x());
     __syncthreads();                                                     // the only workgroup barrier of the launch
+    if (probe) { g_w_probe[3] = __builtin_amdgcn_s_memtime() - t_in; g_w_probe[0] = g_w_probe[1] = g_w_probe[2] = 0; }
     const int envs = FULLWG ? mw::WG_ENVS : min(mw::WG_ENVS, a.S - (int)blockIdx.x * mw::WG_ENVS);
     for (int t = 0; t < c.n_steps; ++t) {
         asm volatile("" ::: "memory");                                   // keep each step's loads inside the step
@@ -42,9 +50,11 @@ __global__ __launch_bounds__(256) void rollout_w_kernel(mf::FwdArgs a, mw::Weigh
         at.probs = a.probs ? a.probs + t * c.probs : nullptr;
         at.attn = a.attn ? a.attn + t * c.attn : nullptr;
         EnvPre pre{};
+        const unsigned long long t0 = probe ? __builtin_amdgcn_s_memtime() : 0ull;
         if constexpr (PRE) pre = env_prefetch<CM_PP, LPE>(p, b_raw, live);   // env state requested in front of the policy forward
         mw::policy_tile_w<LHOPS>(at, w.n_act, res, lds_w, blockIdx.x, act);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // this wave's action words are in LDS
+        const unsigned long long t1 = probe ? __builtin_amdgcn_s_memtime() : 0ull;
         cm_step_out ot = out;
         if (ot.obs) ot.obs += t * c.obs;
         if (ot.reward) ot.reward += t * c.reward;
@@ -68,6 +78,7 @@ __global__ __launch_bounds__(256) void rollout_w_kernel(mf::FwdArgs a, mw::Weigh
         // the CU's vector L1 is write-through and shared, so workgroup scope needs no cache maintenance (as rollout_chunk_kernel)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (probe) { const unsigned long long t2 = __builtin_amdgcn_s_memtime(); g_w_probe[0] += 1; g_w_probe[1] += t1 - t0; g_w_probe[2] += t2 - t1; }
     }
 }
 
@@ -101,6 +112,11 @@ int launch_rollout_w(mf::FwdArgs a, const cm_policy_weights *w, const void *w_pa
 #undef CM_RW2
 #undef CM_RW
     CM_HIP(hipGetLastError());
+    if (d.stop == -2) {
+        unsigned long long hp[4];
+        if (hipStreamSynchronize((hipStream_t)stream) == hipSuccess && hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_w_probe), sizeof(hp)) == hipSuccess && hp[0])
+            fprintf(stderr, "[rollout_w probe] steps=%llu staging=%llu clk; per step: policy=%llu env=%llu clk\n", hp[0], hp[3], hp[1] / hp[0], hp[2] / hp[0]);
+    }
     return CM_OK;
 }
 

@@ -151,3 +151,33 @@ def test_fused_step_kernels_use_no_flat_or_scratch_addressing(tmp_path):
     assert seen >= 10, seen                                               # five shapes x two policy bodies (+ the full-workgroup builds)
     for m in re.finditer(r"^(_ZN2cm19rollout_step_kernel\S+):\n(.*?)\n\.Lfunc_end", asm, re.M | re.S):
         assert not re.search(r"^\s+(flat_(load|store|atomic)|scratch_)", m.group(2), re.M), m.group(1)
+
+
+def test_wave_owned_rollout_kernels_use_no_flat_or_scratch_addressing(tmp_path):
+    """The same guard for the default rollout path of teams of 4 (cm_rollout_w.hip: policy forward + sample + env step of a
+    wave's four envs, for a whole chunk of steps per launch): every rollout_w_kernel instantiation must request no private
+    segment, spill nothing and contain no flat / scratch instruction - with 256 VGPRs + ~120 AGPRs in use (one wave per SIMD,
+    the 128 -> 64 head layer resident in registers) this is the kernel closest to the register limit."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "com-marl_amd", "csrc", "cm_rollout_w.hip")
+    out = tmp_path / "cm_rollout_w.s"
+    subprocess.check_call([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-mllvm",
+                           "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize", "-S", "--cuda-device-only", "-w", "-o", str(out), src])
+    asm = out.read_text()
+    seen = 0
+    for blk in re.split(r"\n\s+- \.agpr_count:", asm)[1:]:                 # one metadata block per kernel
+        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+        if "rollout_w_kernel" not in name:
+            continue
+        seen += 1
+        assert re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1) == "0", name
+        assert re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1) == "0", name
+    assert seen == 8, seen                                                # 1 / 2 hops x env prefetch on / off x full / ragged workgroups
+    for m in re.finditer(r"^(_ZN2cm16rollout_w_kernel\S+):\n(.*?)\n\.Lfunc_end", asm, re.M | re.S):
+        assert not re.search(r"^\s+(flat_(load|store|atomic)|scratch_)", m.group(2), re.M), m.group(1)
+        assert len(re.findall(r"^\s+s_barrier", m.group(2), re.M)) == 1, "one workgroup barrier per launch (behind the weight staging)"
