@@ -90,17 +90,22 @@ class _AttentionSoftmax(torch.autograd.Function):
 
 
 class AttentionModule(nn.Module):
-    """'general' attention (attention_module.py:17-51): softmax_j((q W^T) . k_j)."""
+    """attention_module.py:17-51: 'general' softmax_j((q W^T) . k_j) with the learned ``linear_in``, or 'dot'
+    softmax_j(q . k_j) with no parameter at all (:38-41).  ('diff' creates a parameter in the reference's constructor but its
+    forward has no branch for it - it cannot run there either.)"""
 
     def __init__(self, dimensions, attention_type="general"):
         super().__init__()
-        if attention_type != "general":
-            raise NotImplementedError("only attention_type='general' (the runners' default) is built")
+        if attention_type not in ("general", "dot"):
+            raise NotImplementedError("attention_type must be 'general' or 'dot' ('diff' has no forward branch in the reference, "
+                                      "attention_module.py:36-49)")
         self.attention_type = attention_type
-        self.linear_in = HipLinear(dimensions, dimensions, bias=False)
+        if attention_type == "general":
+            self.linear_in = HipLinear(dimensions, dimensions, bias=False)
+        self._dim = dimensions
 
     def forward(self, query):
-        q = self.linear_in(query)
+        q = self.linear_in(query) if self.attention_type == "general" else query
         if query.is_cuda and query.dim() == 3 and query.shape[-1] == 64:
             return _AttentionSoftmax.apply(q, query)             # fused HIP op (cm_attention_forward/backward)
         return torch.softmax(torch.matmul(q, query.transpose(-2, -1)), dim=-1)
@@ -411,7 +416,10 @@ class _FusedNetFn(torch.autograd.Function):
             dq, dE = torch.empty_like(q), torch.empty_like(e)
             L.check(L.lib().cm_attention_backward(S, N, 64, L.ptr(q), L.ptr(e), L.ptr(attn), L.ptr(d_attn), L.ptr(d_res), L.ptr(dhin0),
                                                   L.ptr(dq), L.ptr(dE), L.current_stream()), "cm_attention_backward")
-        deq, g["attention_layer.linear_in.weight"], _ = _lin_bwd(e, net.attention_layer.linear_in.weight, 0, dq, None, True, False)
+        if net.attention_layer.attention_type == "general":
+            deq, g["attention_layer.linear_in.weight"], _ = _lin_bwd(e, net.attention_layer.linear_in.weight, 0, dq, None, True, False)
+        else:
+            deq = dq                                                     # 'dot': Q is E itself
         enc1, enc2 = net.encoder._layers[0].linear, net.encoder._output_layers[0].linear
         # both encoder layers in one pass (the gradient wrt the hidden layer never leaves the workgroup); wide observations
         # (d > 64) take the two layers one by one
@@ -588,7 +596,10 @@ class CommBaseNet(_WeightPack, nn.Module):
         t["enc_b1"] = enc._layers[0].linear.bias
         t["enc_w2t"] = enc._output_layers[0].linear.weight.t()
         t["enc_b2"] = enc._output_layers[0].linear.bias
-        t["attn_wt"] = self.attention_layer.linear_in.weight.t()
+        if self.attention_layer.attention_type == "general":
+            t["attn_wt"] = self.attention_layer.linear_in.weight.t()
+        else:                                   # 'dot': Q = E, i.e. the fused kernels' linear_in is the identity (a constant)
+            t["attn_wt"] = torch.eye(self._embedding_dim, dtype=torch.float32, device=next(self.parameters()).device)
         t["gcn_w"] = torch.stack([g.weight for g in self.gcn_layers]) if len(self.gcn_layers) else None
         t["gcn_b"] = (torch.stack([g.bias for g in self.gcn_layers])
                       if len(self.gcn_layers) and self.gcn_layers[0].bias is not None else None)
@@ -832,7 +843,7 @@ class GaussianMLPModule(nn.Module):
 
 
 class CommBaseCritic(CommBaseNet):
-    """comm_base_critic.py:11-122, aggregator 'sum' (same ctor kwargs as runner_pp_commDP.py:63-74)."""
+    """comm_base_critic.py:11-122, aggregators 'sum' and 'direct' (same ctor kwargs as runner_pp_commDP.py:63-74)."""
 
     def __init__(self, env_spec, n_agents, encoder_hidden_sizes=(128,), embedding_dim=64, decoder_hidden_sizes=(64,),
                  attention_type="general", n_gcn_layers=2, residual=True, gcn_bias=True, share_std=False,
@@ -841,12 +852,20 @@ class CommBaseCritic(CommBaseNet):
                          embedding_dim=embedding_dim, attention_type=attention_type, n_gcn_layers=n_gcn_layers,
                          residual=residual, gcn_bias=gcn_bias, state_include_actions=state_include_actions, name=name,
                          device=device)
-        if aggregator_type != "sum":
-            raise NotImplementedError("only aggregator_type='sum' (the runners' default) is built")
+        if aggregator_type not in ("sum", "direct"):
+            raise ValueError("aggregator_type must be 'sum' or 'direct' (comm_base_critic.py:46-49)")
         self.aggregator_type = aggregator_type
         self._dec_hidden = tuple(decoder_hidden_sizes)
-        self.baseline_aggregator = GaussianMLPModule(embedding_dim, 1, hidden_sizes=decoder_hidden_sizes)
+        # 'sum': one value per agent from its embedding, summed (:110-112).  'direct': ONE value from the concatenated
+        # embeddings of the whole team (:113-116) - the head is then a plain [N * 64] -> 64 -> 1 MLP on the framework's GEMMs
+        # behind the fused trunk kernels (per-layer path; the fused critic kernels carry the per-agent head only)
+        agg_in = embedding_dim if aggregator_type == "sum" else embedding_dim * n_agents
+        self.baseline_aggregator = GaussianMLPModule(agg_in, 1, hidden_sizes=decoder_hidden_sizes)
         self.to(device)
+
+    def sync_weights(self):
+        if self.aggregator_type == "sum":
+            super().sync_weights()                       # 'direct' has no fused kernel, hence no weight pack to refresh
 
     def _head_tensors(self):
         m = self.baseline_aggregator._mean_module
@@ -868,6 +887,11 @@ class CommBaseCritic(CommBaseNet):
 
     def _values_grad(self, obs_n, dist_adj, channels):
         lead, S, obs, adj, ch = self._flatten(obs_n, dist_adj, channels)
+        if self.aggregator_type == "direct":
+            E, H, _ = self.trunk(obs, adj, ch)
+            x = E + H if self.residual else H
+            mean, std = self.baseline_aggregator(x.reshape(S, -1))                   # concatenated embeddings (:113-115)
+            return mean.squeeze(-1).reshape(*lead), std
         if _fused_train_ok(self, obs) and len(self.baseline_aggregator._mean_module._layers) == 1:
             per_agent, _ = _FusedNetFn.apply(self, obs, adj, ch, *self.parameters())  # [S,N] per-agent means
             ag = self.baseline_aggregator
@@ -884,6 +908,9 @@ class CommBaseCritic(CommBaseNet):
         dev = obs.device
         if dev.type != "cuda":
             raise L.CommarlError("critic forward is a HIP kernel: inputs must be CUDA tensors (no CPU fallback)")
+        if self.aggregator_type == "direct":
+            v = self._values_grad(obs, dist_adj, channels)[0]
+            return v if out is None else out.copy_(v.reshape(out.shape))
         N = self._n_agents
         lead = obs.shape[:-1] if obs.shape[-1] == N * self._dec_obs_dim else obs.shape[:-2]
         S = obs.numel() // (N * self._dec_obs_dim)

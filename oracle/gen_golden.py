@@ -626,6 +626,58 @@ def record_variants(env_fix, n_agents, seed=21, take=6, with_grads=True):
     return out
 
 
+def record_net_options(env_fix, n_agents, seed=31, take=4):
+    """The two non-default net options the reference CLI reaches (env_uitils.py:85,88): ``attention_type='dot'``
+    (attention_module.py:38-41: no linear_in, scores = E.E^T) for policy AND critic, and the critic's
+    ``aggregator_type='direct'`` (comm_base_critic.py:48-49,84-87,115-118: one MLP over the concatenated embeddings).
+    At seeded state_dicts on observations of an env fixture: forward outputs and the gradients of a PPO-shaped scalar
+    (policy) / the Gaussian NLL (critic) with respect to every parameter."""
+    ns = ref_loader.load_reference()
+    T1 = env_fix['obs'].shape[0]
+    d_total = env_fix['obs'].shape[2]
+    spec = ref_loader.make_env_spec(d_total)
+    idx = np.linspace(0, T1 - 1, take).astype(int)
+    obs = env_fix['obs'][idx].reshape(-1, d_total).astype(np.float32)
+    adj = env_fix['dist_adj'][idx].reshape(-1, n_agents, n_agents).astype(np.float32)
+    ch = env_fix['channels'][idx].reshape(-1, env_fix['channels'].shape[2], n_agents, n_agents).astype(np.float32)
+    S = obs.shape[0]
+    rng = np.random.RandomState(seed)
+    acts = rng.randint(0, 5, size=(S, n_agents))
+    wts = rng.randn(S).astype(np.float32)
+    returns = (rng.randn(S) * 3).astype(np.float32)
+    avail = np.ones((S, n_agents * 5), dtype=np.float32)
+    out = dict(obs=obs, adj=adj, channels=ch, actions=acts, weights=wts, returns=returns)
+    tobs, tav, tadj, tch = (torch.Tensor(obs), torch.Tensor(avail), torch.Tensor(adj.reshape(S, -1)),
+                            torch.Tensor(ch.reshape(S, -1, n_agents)))
+    for tag, att, agg in (('dot', 'dot', 'sum'), ('direct', 'general', 'direct')):
+        torch.manual_seed(seed + len(tag))
+        pol = ns.CommCategoricalMLPPolicy(spec, n_agents=n_agents, attention_type=att)
+        crit = ns.CommBaseCritic(spec, n_agents=n_agents, attention_type=att, aggregator_type=agg)
+        with torch.no_grad():
+            for net in (pol, crit):
+                for name, p in net.named_parameters():
+                    if name.endswith('bias') and 'gcn' not in name:
+                        p.uniform_(-0.1, 0.1)
+        with torch.no_grad():
+            dist, attn = pol.forward(obs, avail, adj, ch, get_actions=True)
+            out[f'{tag}.probs'], out[f'{tag}.attn'] = dist.probs.numpy(), attn.numpy()
+            out[f'{tag}.values'] = crit.forward(tobs, tav, tadj, tch).numpy()
+        scalar = -(pol.log_likelihood(tobs, tav, tadj, tch, torch.Tensor(acts)) * torch.Tensor(wts)).mean() \
+            - 0.1 * pol.entropy(tobs, tav, tadj, tch).mean()
+        pol.zero_grad()
+        scalar.backward()
+        loss = crit.compute_loss(tobs, torch.Tensor(returns), tadj, tch)
+        crit.zero_grad()
+        loss.backward()
+        out[f'{tag}.scalar'], out[f'{tag}.critic_loss'] = scalar.detach().numpy(), loss.detach().numpy()
+        for pre, net in (('pol', pol), ('crit', crit)):
+            for name, p in net.state_dict().items():
+                out[f'{tag}.{pre}.{name}'] = p.numpy()
+            for name, p in net.named_parameters():
+                out[f'{tag}.g{pre}.{name}'] = (p.grad if p.grad is not None else torch.zeros_like(p)).clone().numpy()
+    return out
+
+
 def record_ppo_math(ns, seed=5):
     """GAE / returns / per-path normalisation on a ragged 3-path batch."""
     rng = np.random.RandomState(seed)
@@ -783,7 +835,7 @@ def main():
         print(f'{name:28s} {os.path.getsize(path) / 1024:8.1f} KiB')
 
     fx = {}
-    if args.only and args.only.startswith(('ppo_step', 'variants_', 'ppo_math', 'adam', 'adj_ties_grid32', 'faults_direct', 'env_pp_map10_cond')):
+    if args.only and args.only.startswith(('ppo_step', 'variants_', 'ppo_math', 'adam', 'adj_ties_grid32', 'faults_direct', 'env_pp_map10_cond', 'net_options_')):
         return late(save, args)
     # config 1/2: PP map10 sen1 den.04 cap2 (full 200-step horizon, chasing so captures happen)
     fx['pp_map10_cap2'] = record_env(ns, 'pp', pp_params(10, 1, 0.04, 2), B=3, T=230, seed=1, p_random=0.35)
@@ -858,6 +910,8 @@ def late(save, args, ns=None):
     save('variants_pp_map10', lambda: record_variants(np.load(os.path.join(args.out, 'env_pp_map10_cap2.npz')), 4))
     save('variants_co_map20', lambda: record_variants(np.load(os.path.join(args.out, 'env_co_map20.npz')), 24, take=3))
     save('variants_pp_map30', lambda: record_variants(np.load(os.path.join(args.out, 'env_pp_map30_cap4.npz')), 72, take=2))
+    save('net_options_pp_map10', lambda: record_net_options(np.load(os.path.join(args.out, 'env_pp_map10_cap2.npz')), 4))
+    save('net_options_co_map20', lambda: record_net_options(np.load(os.path.join(args.out, 'env_co_map20.npz')), 24, seed=33, take=2))
 
 
 if __name__ == '__main__':

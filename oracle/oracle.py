@@ -292,7 +292,9 @@ def policy_forward(sd, obs, avail, dist_adj, channels, n_agents, n_threads=1, wa
     obs = _f32(obs).reshape(S, N, -1)
     d = obs.shape[2]
     n_hops = channels.shape[-3]
-    arrs = {k: _f32(sd[v]) for k, v in _POL_KEYS.items()}
+    arrs = {k: _f32(sd[v]) for k, v in _POL_KEYS.items() if v in sd}
+    if "attn_w" not in arrs:                 # attention_type='dot' (attention_module.py:38-41): no linear_in, Q = E
+        arrs["attn_w"] = np.eye(arrs["enc_w2"].shape[0], dtype=np.float32)
     arrs["gcn_w"], arrs["gcn_b"] = _gcn_stack(sd, n_hops)
     A = arrs["hd_w4"].shape[0]
     w = PolicyW()
@@ -317,7 +319,12 @@ def critic_forward(sd, obs, dist_adj, channels, n_agents, n_threads=1, residual=
     N = n_agents
     obs = _f32(obs).reshape(S, N, -1)
     n_hops = channels.shape[-3]
-    arrs = {k: _f32(sd[v]) for k, v in _CRIT_KEYS.items()}
+    w1 = sd["baseline_aggregator._mean_module._layers.0.linear.weight"]
+    if w1.shape[1] != sd["encoder._output_layers.0.linear.weight"].shape[0]:
+        return critic_forward_direct(sd, obs, dist_adj, channels, n_agents, n_threads, residual)
+    arrs = {k: _f32(sd[v]) for k, v in _CRIT_KEYS.items() if v in sd}
+    if "attn_w" not in arrs:
+        arrs["attn_w"] = np.eye(arrs["enc_w2"].shape[0], dtype=np.float32)
     arrs["gcn_w"], arrs["gcn_b"] = _gcn_stack(sd, n_hops)
     w = CriticW()
     w.d, w.n_agents, w.n_hops = obs.shape[2], N, n_hops
@@ -330,6 +337,23 @@ def critic_forward(sd, obs, dist_adj, channels, n_agents, n_threads=1, residual=
     values = np.zeros(S, np.float32)
     lib().cmo_critic_forward(C.byref(w), S, _p(obs), _p(adj), _p(ch), _p(values), n_threads)
     return values
+
+
+def critic_forward_direct(sd, obs, dist_adj, channels, n_agents, n_threads=1, residual=True):
+    """aggregator_type='direct' (comm_base_critic.py:113-116): the trunk's x = E + H_L of all agents concatenated, one MLP
+    [N * 64] -> hidden -> 1 on top.  Trunk through the C restatement (cmo_policy_forward's embeddings, its head unused)."""
+    S, N = obs.shape[0], n_agents
+    fake = {k: v for k, v in sd.items() if not k.startswith("baseline_aggregator")}
+    for i, (o, k) in enumerate(((128, 64), (64, 128), (32, 64))):
+        fake[f"categorical_output_layer._layers.{i}.linear.weight"] = np.zeros((o, k), np.float32)
+        fake[f"categorical_output_layer._layers.{i}.linear.bias"] = np.zeros(o, np.float32)
+    fake["categorical_output_layer._output_layers.0.linear.weight"] = np.zeros((5, 32), np.float32)
+    fake["categorical_output_layer._output_layers.0.linear.bias"] = np.zeros(5, np.float32)
+    _, _, emb = policy_forward(fake, obs, np.ones((S, N, 5), np.float32), dist_adj, channels, N, n_threads, want_emb=True,
+                               residual=residual)
+    x = emb[:, 0] + emb[:, -1] if residual else emb[:, -1]              # [S, N, 64]
+    pre = "baseline_aggregator._mean_module."
+    return mlp_forward(_mlp_layers(sd, pre, _n_hidden(sd, pre)), x.reshape(S, -1))[:, 0]
 
 
 def mlp_forward(layers, x):
