@@ -122,7 +122,8 @@ extern "C" int cm_env_create(const cm_env_cfg *cfg, cm_env_t *out) {
     if (c.scenario != CM_PP && c.scenario != CM_CO) return set_error(CM_ERR_ARG, "scenario must be CM_PP or CM_CO");
     if (c.n_envs <= 0 || c.n_agents <= 0 || c.n_agents > 255) return set_error(CM_ERR_ARG, "n_envs > 0 and 0 < n_agents <= 255 required");
     const int S = c.scenario == CM_PP ? c.grid : c.grid + 2;
-    if (S < 2 || S > 32) return set_error(CM_ERR_ARG, "grid side (incl. wall ring) must be in [2, 32]: visited rows are 32-bit masks");
+    if (S < 2 || S > 64) return set_error(CM_ERR_ARG, "grid side (incl. wall ring) must be in [2, 64]: cell coordinates travel as 6-bit fields, "
+                                                     "visited rows as one or two 32-bit words");
     if (c.scenario == CM_PP && (c.n_preys < 0 || c.n_preys > 255)) return set_error(CM_ERR_ARG, "0 <= n_preys <= 255 required");
     if (c.scenario == CM_PP && (c.load < 2 || c.load > 4)) return set_error(CM_ERR_LOAD, "PP load must be 2, 3 or 4 (capv undefined otherwise, predator_prey.py:77-79)");
     if (c.scenario == CM_CO && c.grid % 10 != 0) return set_error(CM_ERR_ARG, "CO map must be a multiple of 10 (coverage.py:67)");
@@ -181,7 +182,7 @@ extern "C" int cm_env_create(const cm_env_cfg *cfg, cm_env_t *out) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~size_t(255); return o; };
     const size_t o_ap = take(B * N * sizeof(int2)), o_pp = take(B * (M ? M : 1) * sizeof(int2)), o_al = take(B * (M ? M : 1)),
-                 o_vis = take(B * S * 4), o_sc = take(B * 4), o_tc = take(B * 4), o_su = take(B * 4),
+                 o_vis = take(B * S * ((S + 31) / 32) * 4), o_sc = take(B * 4), o_tc = take(B * 4), o_su = take(B * 4),
                  o_ge = take(c.channel == CM_CH_GE ? B * N * N : 1), o_rs = take(B * 4), o_ac = take(B * N), o_st = take(4),
                  o_bg = take((size_t)S * S), o_lr = take(S * 4), o_lc = take(S * 4), o_ls = take((c.max_steps + 1) * 4),
                  o_rl = take(rew_lut.size() * 8);
@@ -337,7 +338,7 @@ static int copy_state(cm_env_t h, const cm_env_state *s, bool to_host) {
     struct Item { void *host; void *dev; size_t bytes; };
     const Item items[] = {
         { s->agent_pos, d.agent_pos, B * N * 8 }, { s->prey_pos, d.prey_pos, B * M * 8 }, { s->prey_alive, d.alive, B * M },
-        { s->visited, d.visited, B * S * 4 }, { s->step_count, d.step_count, B * 4 }, { s->total_capture, d.total_capture, B * 4 },
+        { s->visited, d.visited, B * S * ((S + 31) / 32) * 4 }, { s->step_count, d.step_count, B * 4 }, { s->total_capture, d.total_capture, B * 4 },
         { s->success, d.success, B * 4 }, { s->ge_state, d.ge_state, d.channel == CM_CH_GE ? B * N * N : 0 },
         { s->rng_step, d.rng_step, B * 4 } };
     for (const Item &it : items) {

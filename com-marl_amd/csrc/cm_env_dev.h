@@ -44,7 +44,7 @@ struct Lds {           // byte offsets into smem (kept in registers: always pass
     int alive;         // [M] u8
     int pcnt;          // [M] u8 predator count around prey j
     int pmv;           // [M] u8 chosen prey move | 8 = tape ran out
-    int vis;           // [S] u32
+    int vis, vw;       // [S * vw] u32 visited bitmap: vw = ceil(S / 32) words per grid row (bit c & 31 of word r * vw + (c >> 5))
     int own, win, st;  // parallel agent resolution: [S*S] u8 owner index + 1, [S*S] u32 lowest contender, [N] u8 status
 #ifdef CM_BOUNDS
     int nS2, nN, nM, nS;
@@ -56,7 +56,7 @@ __host__ __device__ inline int lds_take(int &off, int bytes) { const int o = off
 __host__ __device__ inline int lds_env_bytes(int S, int N, int M) {
     int off = 0;
     lds_take(off, S * S); lds_take(off, 2 * N); lds_take(off, 2 * N); lds_take(off, 2 * M); lds_take(off, 2 * M);
-    lds_take(off, N); lds_take(off, M); lds_take(off, M); lds_take(off, M); lds_take(off, 4 * S);
+    lds_take(off, N); lds_take(off, M); lds_take(off, M); lds_take(off, M); lds_take(off, 4 * S * ((S + 31) >> 5));
     lds_take(off, S * S); lds_take(off, 4 * S * S); lds_take(off, N);
     return off;
 }
@@ -65,10 +65,10 @@ __device__ __forceinline__ Lds make_lds(int S, int N, int M, int base, int32_t *
     Lds l;
     l.g = lds_take(off, S * S); l.ar = lds_take(off, 2 * N); l.ac = lds_take(off, 2 * N); l.pr = lds_take(off, 2 * M);
     l.pc = lds_take(off, 2 * M); l.act = lds_take(off, N); l.alive = lds_take(off, M); l.pcnt = lds_take(off, M);
-    l.pmv = lds_take(off, M); l.vis = lds_take(off, 4 * S);
+    l.pmv = lds_take(off, M); l.vw = (S + 31) >> 5; l.vis = lds_take(off, 4 * S * l.vw);
     l.own = lds_take(off, S * S); l.win = lds_take(off, 4 * S * S); l.st = lds_take(off, N);
 #ifdef CM_BOUNDS
-    l.nS2 = S * S; l.nN = N; l.nM = M; l.nS = S; l.status = status;
+    l.nS2 = S * S; l.nN = N; l.nM = M; l.nS = S * ((S + 31) >> 5); l.status = status;
 #endif
     return l;
 }
@@ -97,7 +97,9 @@ __device__ __forceinline__ uint8_t &PMV(const Lds l, int i) { return smem[l.pmv 
 __device__ __forceinline__ uint8_t &OWN(const Lds l, int i) { return smem[l.own + chk(l, i, nS2, 12)]; }
 __device__ __forceinline__ uint32_t &WIN(const Lds l, int i) { return reinterpret_cast<uint32_t *>(smem + l.win)[chk(l, i, nS2, 13)]; }
 __device__ __forceinline__ uint8_t &ST(const Lds l, int i) { return smem[l.st + chk(l, i, nN, 14)]; }
-__device__ __forceinline__ uint32_t &VIS(const Lds l, int i) { return reinterpret_cast<uint32_t *>(smem + l.vis)[chk(l, i, nS, 10)]; }
+__device__ __forceinline__ uint32_t &VIS(const Lds l, int i) { return reinterpret_cast<uint32_t *>(smem + l.vis)[chk(l, i, nS, 10)]; }   // word i
+__device__ __forceinline__ uint32_t &VISW(const Lds l, int r, int c) { return VIS(l, r * l.vw + (c >> 5)); }                        // word of cell (r, c)
+__device__ __forceinline__ uint32_t vbit(int c) { return 1u << (c & 31); }
 
 // Branch-free probes: the address is clamped into the tile and the result masked by the bounds test, so the
 // four neighbour reads of count_adj are independent LDS loads (one round trip) instead of four dependent
@@ -166,7 +168,7 @@ __device__ __forceinline__ void do_reset(const EnvDev &p, const Lds l, const Rng
     const int S = p.S, N = p.N, M = p.M, sl = g.sl;
     if (need) {
         for (int k = sl; k < S * S; k += LPE) Gc(l, k) = (SCEN == CM_CO) ? p.base_grid[k] : (uint8_t)C_EMPTY;
-        if (SCEN == CM_CO) for (int r = sl; r < S; r += LPE) VIS(l, r) = 0u;
+        if (SCEN == CM_CO) for (int r = sl; r < S * l.vw; r += LPE) VIS(l, r) = 0u;
     }
     ENV_SYNC();
     const int lo = (SCEN == CM_CO) ? 1 : 0;                              // randint(1, m) vs randint(0, G-1)
@@ -201,7 +203,7 @@ __device__ __forceinline__ void do_reset(const EnvDev &p, const Lds l, const Rng
         ENV_SYNC();                                   // all probes done before anybody commits
         if (ok && sl == 0) {
             if (!is_prey) { AR(l, e) = (int16_t)r; AC(l, e) = (int16_t)c; Gc(l, r * S + c) = C_AGENT;
-                            if (SCEN == CM_CO) VIS(l, r) |= (1u << c); }          // coverage.py:187
+                            if (SCEN == CM_CO) VISW(l, r, c) |= vbit(c); }          // coverage.py:187
             else { PR(l, e - N) = (int16_t)r; PC(l, e - N) = (int16_t)c; Gc(l, r * S + c) = C_PREY; }
         }
         ENV_SYNC();
@@ -253,7 +255,7 @@ __device__ __forceinline__ void emit(const EnvDev &p, const Lds l, const Rng rng
                     const bool in = in_grid(rr, cc, S);
                     if (chn == 0) v = (!in || Gc(l, rr * S + cc) == C_WALL) ? 1.0f : 0.0f;
                     else if (chn == 1) v = (in && Gc(l, rr * S + cc) == C_AGENT) ? 1.0f : 0.0f;
-                    else v = (in && ((VIS(l, rr) >> cc) & 1u)) ? 1.0f : 0.0f;
+                    else v = (in && ((VISW(l, rr, cc) >> (cc & 31)) & 1u)) ? 1.0f : 0.0f;
                 } else v = f == 3 * WW ? vrow : (f == 3 * WW + 1 ? vcol : tabs.step);      // (:206)
             }
             if (on) o[k] = v;
@@ -279,7 +281,7 @@ __device__ __forceinline__ void emit(const EnvDev &p, const Lds l, const Rng rng
                     const bool in = in_grid(rr, cc, S);
                     if (chn == 0) v = (!in || Gc(l, rr * S + cc) == C_WALL) ? 1.0f : 0.0f;
                     else if (chn == 1) v = (in && Gc(l, rr * S + cc) == C_AGENT) ? 1.0f : 0.0f;
-                    else v = (in && ((VIS(l, rr) >> cc) & 1u)) ? 1.0f : 0.0f;
+                    else v = (in && ((VISW(l, rr, cc) >> (cc & 31)) & 1u)) ? 1.0f : 0.0f;
                 } else if (f == 3 * WW) v = p.lut_row[r0];          // round(row/(S-1), 2) (:206)
                 else if (f == 3 * WW + 1) v = p.lut_col[c0];
                 else v = p.lut_step[step_count];
@@ -396,7 +398,7 @@ __device__ __forceinline__ void emit(const EnvDev &p, const Lds l, const Rng rng
             p.alive[(size_t)b * M + j] = ALV(l, j);
         }
     } else {
-        for (int r = sl; r < S; r += LPE) p.visited[(size_t)b * S + r] = VIS(l, r);
+        for (int r = sl; r < S * l.vw; r += LPE) p.visited[(size_t)b * S * l.vw + r] = VIS(l, r);
     }
 }
 
@@ -480,7 +482,7 @@ __device__ __forceinline__ MoveOut agents_parallel(const EnvDev &p, const Lds l,
         const int i = sl + q * LPE;
         const bool is = i < N, moved = st[q] == 1;
         seen[q] = false;
-        if (SCEN == CM_CO && moved) { const int X = tgt[q], nr = fdiv(X, S, 1.0f / (float)S); seen[q] = (VIS(l, nr) >> (X - nr * S)) & 1u; }
+        if (SCEN == CM_CO && moved) { const int X = tgt[q], nr = fdiv(X, S, 1.0f / (float)S); seen[q] = (VISW(l, nr, X - nr * S) >> ((X - nr * S) & 31)) & 1u; }
         mo.moving += g.count(is && act[q] != 4);
         mo.lazy += g.count(is && act[q] == 4);
         mo.pen += g.count(is && act[q] != 4 && !moved);
@@ -497,7 +499,7 @@ __device__ __forceinline__ MoveOut agents_parallel(const EnvDev &p, const Lds l,
             const int X = tgt[q], nr = fdiv(X, S, 1.0f / (float)S), nc = X - nr * S;
             Gc(l, X) = C_AGENT;
             AR(l, sl + q * LPE) = (int16_t)nr; AC(l, sl + q * LPE) = (int16_t)nc;
-            if (SCEN == CM_CO) atomicOr(&VIS(l, nr), 1u << nc);
+            if (SCEN == CM_CO) atomicOr(&VISW(l, nr, nc), vbit(nc));
         }
     }
     ENV_SYNC();
@@ -833,7 +835,7 @@ __device__ __forceinline__ void env_body(const EnvDev &p, const int32_t *__restr
         }
     }
     for (int k = sl; k < S * S; k += LPE) Gc(l, k) = (SCEN == CM_CO) ? p.base_grid[k] : (uint8_t)C_EMPTY;
-    if (SCEN == CM_CO) for (int r = sl; r < S; r += LPE) VIS(l, r) = p.visited[(size_t)b * S + r];
+    if (SCEN == CM_CO) for (int r = sl; r < S * l.vw; r += LPE) VIS(l, r) = p.visited[(size_t)b * S * l.vw + r];
     // the reference raises on a bad action (predator_prey.py:255): flag it; the env is left untouched
     const bool env_bad = g.any(bad_action);
     if (env_bad && sl == 0 && valid) raise(p, CM_ERR_ACTION);
@@ -1060,12 +1062,12 @@ __device__ __forceinline__ void env_body(const EnvDev &p, const int32_t *__restr
                 ++mov;
                 r = AR(l, i); c = AC(l, i); nr = r + dr_of(a); nc = c + dc_of(a);
                 mv = in_grid(nr, nc, S) && Gc(l, nr * S + nc) == C_EMPTY;
-                if (mv) { seen = (VIS(l, nr) >> nc) & 1u; if (seen) ++rev; else ++cap; }
+                if (mv) { seen = (VISW(l, nr, nc) >> (nc & 31)) & 1u; if (seen) ++rev; else ++cap; }
                 else ++pen;
             }
             ENV_SYNC();
             if (mv && sl == 0) {
-                VIS(l, nr) |= (1u << nc);
+                VISW(l, nr, nc) |= vbit(nc);
                 Gc(l, r * S + c) = C_EMPTY; Gc(l, nr * S + nc) = C_AGENT; AR(l, i) = (int16_t)nr; AC(l, i) = (int16_t)nc;
             }
             ENV_SYNC();

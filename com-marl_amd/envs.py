@@ -184,7 +184,8 @@ class GridEnvBatch:
     def get_state(self):
         B, N, M, S = self.B, self.N, max(self.M, 1), self.S
         st = dict(agent_pos=np.zeros((B, N, 2), np.int32), prey_pos=np.zeros((B, M, 2), np.int32),
-                  prey_alive=np.zeros((B, M), np.uint8), visited=np.zeros((B, S), np.uint32),
+                  prey_alive=np.zeros((B, M), np.uint8),
+                  visited=np.zeros((B, S) if S <= 32 else (B, S, (S + 31) // 32), np.uint32),   # row bitmasks: 2 words from map 40 on
                   step_count=np.zeros(B, np.int32), total_capture=np.zeros(B, np.int32),
                   success=np.zeros(B, np.int32), ge_state=np.zeros((B, N, N), np.uint8),
                   rng_step=np.zeros(B, np.uint32))

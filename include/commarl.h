@@ -108,7 +108,8 @@ typedef struct cm_env_state {
     int32_t *agent_pos;      /* [B,N,2] */
     int32_t *prey_pos;       /* [B,M,2] */
     uint8_t *prey_alive;     /* [B,M] */
-    uint32_t *visited;       /* [B,S] one bitmask per grid row (CO) */
+    uint32_t *visited;       /* [B,S,W] row bitmasks (CO): W = ceil(S / 32) words per grid row - [B,S] up to map 30; cell (r, c) =
+                              * bit c & 31 of word (r, c >> 5) */
     int32_t *step_count;     /* [B] */
     int32_t *total_capture;  /* [B] */
     int32_t *success;        /* [B] */

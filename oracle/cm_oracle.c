@@ -160,6 +160,12 @@ typedef struct env_view {
     uint8_t *cond;           /* agent_condition of this env, or NULL */
 } env_view;
 
+/* visited bitmap: VW = ceil(S / 32) words per grid row; cell (r, c) = bit c & 31 of word r * VW + (c >> 5) - one word per row
+ * up to map 30, two for maps 40 / 50 (the reference keeps a float map, coverage.py:44,165-168) */
+#define VW(S) (((S) + 31) >> 5)
+static int vis_get(const env_view *e, int r, int c) { return (int)((e->visited[r * VW(e->S) + (c >> 5)] >> (c & 31)) & 1u); }
+static void vis_set(env_view *e, int r, int c) { e->visited[r * VW(e->S) + (c >> 5)] |= 1u << (c & 31); }
+
 static int in_grid(const env_view *e, int r, int c) { return r >= 0 && r < e->S && c >= 0 && c < e->S; }
 /* _is_cell_vacant (predator_prey.py:234-238, coverage.py:258-259) */
 static int vacant(const env_view *e, int r, int c) { return in_grid(e, r, c) && e->grid[r * e->S + c] == C_EMPTY; }
@@ -169,7 +175,7 @@ static void view_init(env_view *e, const cmo_cfg *cfg, cmo_state *st, int b) {
     e->apos = st->agent_pos + (size_t)b * e->N * 2;
     e->ppos = st->prey_pos ? st->prey_pos + (size_t)b * e->M * 2 : NULL;
     e->alive = st->prey_alive ? st->prey_alive + (size_t)b * e->M : NULL;
-    e->visited = st->visited ? st->visited + (size_t)b * e->S : NULL;
+    e->visited = st->visited ? st->visited + (size_t)b * e->S * VW(e->S) : NULL;
     e->step_count = st->step_count + b;
     e->total_capture = st->total_capture ? st->total_capture + b : NULL;
     e->success = st->success + b;
@@ -337,7 +343,7 @@ static void co_obs(const env_view *e, float *obs) {
                 uint8_t g = e->grid[row * S + col];
                 if (g == C_WALL) o[k] = 1.0f;
                 if (g == C_AGENT) o[W * W + k] = 1.0f;
-                if ((e->visited[row] >> col) & 1u) o[2 * W * W + k] = 1.0f;
+                if (vis_get(e, row, col)) o[2 * W * W + k] = 1.0f;
             }
         o[3 * W * W + 0] = (float)py_round2((double)r0 / (double)(S - 1));        /* :206 */
         o[3 * W * W + 1] = (float)py_round2((double)c0 / (double)(S - 1));
@@ -377,7 +383,7 @@ static void pp_reset(env_view *e, rng_ctx *rc) {
 static void co_reset(env_view *e, rng_ctx *rc) {
     const int S = e->S, m = e->cfg->grid;
     co_base_grid(e->cfg, e->grid);
-    for (int r = 0; r < S; ++r) e->visited[r] = 0;
+    for (int r = 0; r < S * VW(S); ++r) e->visited[r] = 0;
     for (int i = 0; i < e->N && !rc->err; ++i)
         for (;;) {
             int r, c;
@@ -385,7 +391,7 @@ static void co_reset(env_view *e, rng_ctx *rc) {
             if (rc->err) break;
             if (vacant(e, r, c)) {
                 e->apos[2 * i] = r; e->apos[2 * i + 1] = c; e->grid[r * S + c] = C_AGENT;
-                e->visited[r] |= (1u << c);
+                vis_set(e, r, c);
                 break;
             }
         }
@@ -516,7 +522,7 @@ static int co_step(env_view *e, const int32_t *act, int n_empty, double *reward,
         int r = e->apos[2 * i], c = e->apos[2 * i + 1], nr = r + DR[a], nc = c + DC[a];
         if (vacant(e, nr, nc)) {
             e->apos[2 * i] = nr; e->apos[2 * i + 1] = nc;
-            if (!((e->visited[nr] >> nc) & 1u)) { e->visited[nr] |= (1u << nc); cap++; }
+            if (!vis_get(e, nr, nc)) { vis_set(e, nr, nc); cap++; }
             else rev++;
             e->grid[r * S + c] = C_EMPTY; e->grid[nr * S + nc] = C_AGENT;
         } else pen++;

@@ -835,7 +835,7 @@ def main():
         print(f'{name:28s} {os.path.getsize(path) / 1024:8.1f} KiB')
 
     fx = {}
-    if args.only and args.only.startswith(('ppo_step', 'variants_', 'ppo_math', 'adam', 'adj_ties_grid32', 'faults_direct', 'env_pp_map10_cond', 'net_options_')):
+    if args.only and args.only.startswith(('ppo_step', 'variants_', 'ppo_math', 'adam', 'adj_ties_grid32', 'faults_direct', 'env_pp_map10_cond', 'net_options_', 'env_pp_map40', 'env_co_map40')):
         return late(save, args)
     # config 1/2: PP map10 sen1 den.04 cap2 (full 200-step horizon, chasing so captures happen)
     fx['pp_map10_cap2'] = record_env(ns, 'pp', pp_params(10, 1, 0.04, 2), B=3, T=230, seed=1, p_random=0.35)
@@ -902,6 +902,11 @@ def late(save, args, ns=None):
     save('env_pp_map10_cond', lambda: record_env(ns, 'pp', pp_params(10, 1, 0.04, 2, max_env_steps=12), B=4, T=30, seed=21,
                                                  p_random=0.6, agent_condition=np.array([[1, 0, 1, 0], [0, 0, 0, 0],
                                                                                           [1, 1, 1, 1], [0, 1, 1, 1]])))
+    # maps beyond 32 cells a side (README.md:50,76 "10, 20, 30, or multiples of 10"; utils_pp.py:55-65 has a >= 40 branch):
+    # PP map 40 den .08 -> N = M = 128, CO map 40 den .06 -> N = 96 on a 42 x 42 grid (visited rows take two 32-bit words)
+    save('env_pp_map40_cap4', lambda: record_env(ns, 'pp', pp_params(40, 2, 0.08, 4, max_env_steps=9), B=2, T=12, seed=41,
+                                                 p_random=0.3))
+    save('env_co_map40', lambda: record_env(ns, 'co', co_params(40, 2, 0.06, max_env_steps=8), B=2, T=11, seed=42, p_random=1.0))
     save('ppo_math', lambda: record_ppo_math(ns))
     save('adam', lambda: record_adam(ns))
     save('ppo_step', lambda: record_ppo_step())

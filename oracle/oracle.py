@@ -157,7 +157,8 @@ class OracleEnv:
         self.agent_pos = np.zeros((B, N, 2), np.int32)
         self.prey_pos = np.zeros((B, M, 2), np.int32)
         self.prey_alive = np.zeros((B, M), np.uint8)
-        self.visited = np.zeros((B, self.S), np.uint32)
+        self.VW = (self.S + 31) // 32                       # words per visited row (2 from map 40 on)
+        self.visited = np.zeros((B, self.S, self.VW), np.uint32) if self.VW > 1 else np.zeros((B, self.S), np.uint32)
         self.step_count = np.zeros(B, np.int32)
         self.total_capture = np.zeros(B, np.int32)
         self.success = np.zeros(B, np.int32)
@@ -205,7 +206,8 @@ class OracleEnv:
 
     def visited_dense(self):
         cols = np.arange(self.S, dtype=np.uint32)
-        return ((self.visited[:, :, None] >> cols[None, None, :]) & 1).astype(np.uint8)
+        words = self.visited.reshape(self.B, self.S, self.VW)[:, :, cols >> 5]            # [B, S, S]: the word of every column
+        return ((words >> (cols & 31)[None, None, :]) & 1).astype(np.uint8)
 
 
 # --------------------------------------------------------------------------------------

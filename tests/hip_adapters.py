@@ -67,4 +67,6 @@ class HipEnv:
 
     def visited_dense(self):
         cols = np.arange(self.S, dtype=np.uint32)
-        return ((self.visited[:, :, None] >> cols[None, None, :]) & 1).astype(np.uint8)
+        vw = (self.S + 31) // 32
+        words = np.asarray(self.visited).reshape(-1, self.S, vw)[:, :, cols >> 5]
+        return ((words >> (cols & 31)[None, None, :]) & 1).astype(np.uint8)

@@ -195,6 +195,23 @@ def test_bad_action_is_reported(hip):
         e.step(a)
 
 
+def test_philox_map40_teams(hip):
+    """Maps beyond 32 cells a side (README.md:50,76; utils_pp.py:55-65): PP map 40 den .08 cap 4 -> N = M = 128, CO map 40 den .06
+    -> N = 96 on the 42 x 42 grid (two visited words per row), IID loss; every env resets at least once.  The small batches take
+    the 256-thread-per-env form, 1600 envs the one-wave-per-env form."""
+    n = _lockstep(dict(scenario="pp", n_envs=48, n_agents=128, n_preys=128, grid=40, rsen=2, load=4, max_steps=12), steps=30,
+                  hip=hip, check_every=4)
+    assert n >= 48
+    n = _lockstep(dict(scenario="co", n_envs=40, n_agents=96, grid=40, rsen=2, max_steps=400, max_path_length=10, channel="IID",
+                       ploss=0.3), steps=24, hip=hip, check_every=4)
+    assert n >= 40
+    n = _lockstep(dict(scenario="co", n_envs=1600, n_agents=96, grid=40, rsen=2, max_steps=400, max_path_length=6), steps=8,
+                  hip=hip, check_every=7)
+    assert n >= 1600
+    _lockstep(dict(scenario="pp", n_envs=8, n_agents=200, n_preys=200, grid=50, rsen=2, load=4, max_steps=6), steps=9, hip=hip,
+              check_every=2)                                                   # map 50: N = M = 200
+
+
 def test_tape_exhaustion_is_reported(hip):
     cfg = O.make_cfg("pp", 2, 4, 10, 1, n_preys=4, rng_mode=O.RNG_TAPE)
     e = hip.HipEnv(cfg)
@@ -208,7 +225,8 @@ def test_unsupported_config_is_refused(hip):
     with pytest.raises(CommarlError):
         hip.HipEnv(O.make_cfg("pp", 2, 4, 10, 1, n_preys=4, load=5))
     with pytest.raises(CommarlError):
-        hip.HipEnv(O.make_cfg("pp", 2, 4, 40, 1, n_preys=4))     # grid side > 32
+        hip.HipEnv(O.make_cfg("pp", 2, 4, 70, 1, n_preys=4))     # grid side > 64 (cell coordinates travel as 6-bit fields)
+    hip.HipEnv(O.make_cfg("pp", 2, 4, 40, 1, n_preys=4))         # maps 40 ... 60 are built (README.md:50,76)
 
 
 def test_ragged_batch_sizes_and_empty_calls(hip):
