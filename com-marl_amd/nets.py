@@ -25,6 +25,9 @@ from torch.distributions import Categorical, Normal
 from . import _lib as L
 
 
+MAX_KERNEL_AGENTS = 128      # team size up to which the N x N HIP kernels hold one env's matrix in LDS
+MAX_FUSED_AGENTS = 80        # ... and up to which the one-launch forward (rollout and training) does (cm_policy_h_dev.h LDS map)
+
 # ---------------------------------------------------------------------------------------------
 # building blocks with the reference's state_dict names
 # ---------------------------------------------------------------------------------------------
@@ -106,9 +109,9 @@ class AttentionModule(nn.Module):
 
     def forward(self, query):
         q = self.linear_in(query) if self.attention_type == "general" else query
-        if query.is_cuda and query.dim() == 3 and query.shape[-1] == 64:
+        if query.is_cuda and query.dim() == 3 and query.shape[-1] == 64 and query.shape[-2] <= MAX_KERNEL_AGENTS:
             return _AttentionSoftmax.apply(q, query)             # fused HIP op (cm_attention_forward/backward)
-        return torch.softmax(torch.matmul(q, query.transpose(-2, -1)), dim=-1)
+        return torch.softmax(torch.matmul(q, query.transpose(-2, -1)), dim=-1)   # teams above 128 agents (maps >= 50): library GEMMs
 
 
 class GraphConvolutionModule(nn.Module):
@@ -274,6 +277,17 @@ def masked_aggregate(attn, dist_adj, channels, hop, hw, bias):
     """attn [S,N,N], dist_adj [S,N,N] or None (= ones), channels [S,L,N,N] or None, hw [S,N,E]."""
     if not hw.is_cuda:
         raise L.CommarlError("masked_aggregate is a HIP op: tensors must live on the MI355X (no CPU fallback)")
+    if hw.shape[1] > MAX_KERNEL_AGENTS:
+        # teams above 128 agents (PP map 50: N = 200): the N x N tile of one env no longer fits a workgroup's LDS - the same
+        # arithmetic (comm_base_net.py:101-103, graph_conv_module.py:63-70) on the framework's batched GEMM, still on the GPU
+        A = attn
+        if dist_adj is not None:
+            A = A * dist_adj
+        if channels is not None:
+            A = A * channels[:, hop]
+        A = A / (A.sum(dim=-1, keepdim=True) + 1e-12)
+        out = torch.matmul(A, hw)
+        return torch.tanh(out + bias if bias is not None else out)
     return _MaskedAggregate.apply(attn, dist_adj, channels, hop, hw, bias)
 
 
@@ -299,7 +313,7 @@ def _fused_shape_ok(net, obs):
     """Shapes with a saved-forward instantiation (cm_*_forward_saved) and a backward chain."""
     # teams above 80 agents exceed the f16-split forward's LDS budget (its activation planes + the N x N score matrix):
     # they keep the per-layer path
-    return (obs.is_cuda and 1 <= net._n_agents <= 80 and 1 <= len(net.gcn_layers) <= 4
+    return (obs.is_cuda and 1 <= net._n_agents <= MAX_FUSED_AGENTS and 1 <= len(net.gcn_layers) <= 4
             and net._dec_obs_dim <= 96 and len(net.encoder._layers) == 1
             and os.environ.get("COMMARL_FUSED_TRAIN", "1") != "0" and os.environ.get("COMMARL_POLICY_KERNEL", "")[:1] not in ("f", "v"))
 
@@ -764,6 +778,9 @@ class CommCategoricalMLPPolicy(CommBaseNet):
         if policy_step is None:
             policy_step = self._policy_step
             self._policy_step += 1
+        if N > MAX_FUSED_AGENTS:
+            return self._act_device_layers(obs, avail, dist_adj, channels, greedy, actions, probs, attn, policy_step, step_base,
+                                           env_id_offset)
         w = self._weights_struct()
         with torch.cuda.device(dev):
             L.check(L.lib().cm_policy_forward(
@@ -774,6 +791,29 @@ class CommCategoricalMLPPolicy(CommBaseNet):
                 policy_step & 0xFFFFFFFF, L.ptr(step_base), int(greedy), L.ptr(actions), L.ptr(probs), L.ptr(attn),
                 L.current_stream()), "cm_policy_forward")
         return actions, probs, attn
+
+    def _act_device_layers(self, obs, avail, dist_adj, channels, greedy, actions, probs, attn, policy_step, step_base, env_id_offset):
+        """Teams above 80 agents (PP map 40: N = 128; CO map 40: N = 96): one env's activation planes plus its N x N score matrix
+        exceed a workgroup's 160 KB of LDS, so the forward runs layer by layer - encoder on the library GEMM, attention softmax
+        and masked aggregation on their own HIP kernels (the training path's, up to 128 agents) - and the head + softmax x avail
+        + Philox sample as ONE launch of the row-MLP kernel (cm_mlp_policy_forward) over x = E + H_L.  Same Philox site as the
+        fused kernel: the sampled action is the oracle's inverse-CDF draw on the returned probabilities."""
+        N, A, d = self._n_agents, self._action_dim, self._dec_obs_dim
+        S = obs.numel() // (N * d)
+        Lh = len(self.gcn_layers)
+        E, H, M = self.trunk(obs.reshape(S, N, d), None if dist_adj is None else dist_adj.reshape(S, N, N),
+                             None if channels is None else channels.reshape(S, Lh, N, N))
+        x = (E + H if self.residual else H).reshape(S, N * self._embedding_dim).contiguous()
+        hs = getattr(self, "_head_sampler_obj", None)
+        if hs is None:
+            hs = self.__dict__["_head_sampler_obj"] = _HeadSampler(self)       # (not a submodule: no new state_dict entries)
+        hs.seed, hs.env_id_offset = self.seed, self.env_id_offset
+        a_out, p_out, _ = hs.act_device(x, avail, greedy=greedy, want_actions=actions is not None, want_probs=True,
+                                        out_actions=actions, out_probs=probs, policy_step=policy_step, step_base=step_base,
+                                        env_id_offset=env_id_offset)
+        if attn is not None:
+            attn.copy_(M.reshape(attn.shape))
+        return a_out, p_out, attn
 
     @torch.no_grad()
     def step_fused(self, env_batch, obs, dist_adj, channels, step_out, greedy=False, out_actions=None, out_probs=None,
@@ -908,7 +948,7 @@ class CommBaseCritic(CommBaseNet):
         dev = obs.device
         if dev.type != "cuda":
             raise L.CommarlError("critic forward is a HIP kernel: inputs must be CUDA tensors (no CPU fallback)")
-        if self.aggregator_type == "direct":
+        if self.aggregator_type == "direct" or self._n_agents > MAX_FUSED_AGENTS:    # no one-launch kernel: layer by layer
             v = self._values_grad(obs, dist_adj, channels)[0]
             return v if out is None else out.copy_(v.reshape(out.shape))
         N = self._n_agents
@@ -1059,6 +1099,25 @@ class _RowMLPPolicy(_WeightPack):
     @property
     def vectorized(self):
         return True
+
+
+class _HeadSampler(_RowMLPPolicy):
+    """The Comm-DP policy's head (64 -> 128 -> 64 -> 32 -> A, categorical_mlp_module.py:64-80) + softmax x avail + Philox sample as
+    a row-MLP chain over the trunk output x = E + H_L: the rollout forward of teams too large for the one-launch kernel."""
+    _per_agent_rows = True
+
+    def __init__(self, policy):
+        self._policy = policy
+        self._n_agents, self._action_dim = policy._n_agents, policy._action_dim
+        self._dec_obs_dim = self._obs_dim = policy._embedding_dim
+        self.seed, self.env_id_offset, self._policy_step = policy.seed, policy.env_id_offset, 0
+
+    def parameters(self):
+        return self._policy.categorical_output_layer.parameters()
+
+    def _chain(self):
+        h = self._policy.categorical_output_layer
+        return [(l.linear, True) for l in h._layers] + [(h._output_layers[0].linear, False)]
 
 
 class DecCategoricalMLPPolicy(_RowMLPPolicy, MLPModule):
