@@ -264,6 +264,9 @@ def measure_rollout(config, args, rank, world, dev, steps, warmup, envs=None, st
         ev1.synchronize()
         return ev0.elapsed_time(ev1) / (reps * inner) * 1e-3                 # seconds per launch
 
+    if getattr(args, "no_kernel_table", False):
+        return dict(c=c, B=B, env=env, policy=policy, spec=spec, eng=eng, ns=ns, G=G, value=value, dt=dt, n_captured=n_captured,
+                    timed_lengths=timed_lengths, extra_warm=extra_warm, use_graph=use_graph, roofline=None)
     env.reset_all()                                     # full-batch handle: per-launch kernel times at B envs
     adj0 = None if eng.dist_adj is None else eng.dist_adj[0]
     ch0 = None if eng.channels is None else eng.channels[0]
@@ -363,6 +366,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-loop", action="store_true")
+    ap.add_argument("--no-kernel-table", action="store_true",
+                    help="skip the per-kernel HIP-event measurements (profiler runs: every launch of the process is then a launch of "
+                         "the timed region's form)")
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip the BASELINE configs 3-5 that a default single-GPU run times after the headline")
     ap.add_argument("--extra-steps", type=int, default=600, help="timed steps of each extra config")

@@ -112,6 +112,14 @@ int launch_rollout_w(mf::FwdArgs a, const cm_policy_weights *w, const void *w_pa
 #undef CM_RW2
 #undef CM_RW
     CM_HIP(hipGetLastError());
+    if (d.stop == -1) {                                                  // env phase clocks of workgroup 0 (ENV_PROBE, cm_env_dev.h)
+        unsigned long long hp[16];
+        if (hipStreamSynchronize((hipStream_t)stream) == hipSuccess && hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_env_probe), sizeof(hp)) == hipSuccess) {
+            fprintf(stderr, "[rollout_w env probe] clk since env entry:");
+            for (int i = 1; i < 10; ++i) fprintf(stderr, " p%d=%lld", i, (long long)(hp[i] - hp[0]));
+            fprintf(stderr, "\n");
+        }
+    }
     if (d.stop == -2) {
         unsigned long long hp[4];
         if (hipStreamSynchronize((hipStream_t)stream) == hipSuccess && hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_w_probe), sizeof(hp)) == hipSuccess && hp[0])

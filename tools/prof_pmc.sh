@@ -16,7 +16,7 @@ for r in csv.DictReader(open(f)):
     k = (r["Kernel_Name"][:60], r["Counter_Name"])
     acc[k][0] += float(r["Counter_Value"]); acc[k][1] += 1
 for (kn, cn), (s, n) in sorted(acc.items()):
-    if "fwd_mfma" in kn or "env_kernel" in kn or "rollout_step" in kn or "fwd_h_" in kn:
+    if "fwd_mfma" in kn or "env_kernel" in kn or "rollout_step" in kn or "fwd_h_" in kn or "rollout_w" in kn or "fwd_w_" in kn:
         print(f"{kn:62s} {cn:32s} mean {s / n:14.1f} over {n} dispatches")
 PY
 cat $ROOT/gpurun_out/pmc_$TAG.txt
