@@ -330,13 +330,15 @@ def measure_rollout(config, args, rank, world, dev, steps, warmup, envs=None, st
     dom = "cm_rollout_chunk" if t_chunk is not None else (
         "cm_rollout_step" if t_fused is not None else (kname if t_pol >= t_env else "cm_env_step"))
     tr = (traffic or {}).get(dom) if isinstance(traffic, dict) else None
+    if tr is not None and dom == "cm_rollout_chunk":
+        tr = tr * G                                     # the file holds bytes per step; a launch runs G steps
     roofline = dict(kernel=dom, **{k: kernels[dom][k] for k in ("bound", "achieved", "peak", "unit", "frac", "hbm_frac")},
                     traffic=tr,
                     traffic_source=(None if tr is None else
-                                    "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of a builder run on "
-                                    "another MI355X box (not measured by this run); raw counter values, the guide's gfx950 x2 "
-                                    "FETCH_SIZE rule for 16-byte-per-lane reads NOT applied (it would put traffic at <= 1.6x "
-                                    "the algorithmic bytes instead of 1.13x)"),
+                                    "profiles/traffic.json (+ profiles/r03_pmc/): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of a "
+                                    "builder run on another MI355X box (not measured by this run), scaled to this launch's step "
+                                    "count; raw counter values, the guide's gfx950 x2 FETCH_SIZE rule for 16-byte-per-lane reads NOT "
+                                    "applied (the kernel's HBM reads are 4-byte-per-lane state loads)"),
                     note=("peak = dense f32 MFMA (the arithmetic is f32-grade); the instructions issued are three "
                           "v_mfma_f32_16x16x32_f16 per 16x16x32 block on (hi, lo) operand pairs (DESIGN.md §4), whose own ceiling "
                           "is 157.3 x 256/48 = 839 TFLOP/s f32-equivalent: frac_f16_pipe prices the kernel on THAT pipe; "
