@@ -39,7 +39,7 @@ __global__ void pack_layer_w_kernel(const float *__restrict__ Wt, int K, int OUT
         const float w = ((k < K && o >= 0 && o < OUT) ? Wt[(size_t)k * OUT + o] : 0.0f) * scale;
         if (bad && !(fabsf(w) <= 65504.0f)) atomicOr(bad, 1);
         h16 h, l;
-        split2(w, h, l);
+        split_u(w, h, l);                                    // unscaled lo plane (cm_policy_w_dev.h)
         hi[e] = h; lo[e] = l;
     }
     dst[((size_t)blk * 2 + 0) * 64 + lane] = __builtin_bit_cast(uint4, hi);

@@ -35,8 +35,6 @@ using mf::v4f;
 using mf::fast_tanh;
 using mf::EH; using mf::EMB; using mf::H1; using mf::H2; using mf::H3; using mf::MAX_ACT;
 using mh::v8h; using mh::v4h; using mh::h16;
-using mh::LO_SCALE; using mh::LO_INV;
-using mh::split2;
 
 constexpr int WG_ENVS = 16, WG_ROWS = 64, KH = 32;       // teams of 4: 16 envs = 64 rows = 4 wave tiles per workgroup
 constexpr int FRAG = 64;                                 // uint4 per (column tile, k block, plane): one 16-byte chunk per lane
@@ -126,11 +124,14 @@ __device__ __forceinline__ void tanh_stage(float (&v)[N]) {
 #pragma unroll
     for (int i = 0; i < N; ++i) v[i] = fmaf(-2.0f, e[i], 1.0f);
 }
-// y -> (hi, lo) f16 planes:  hi = f16(y), lo = f16((y - hi) 4096).  Pairs go through v_cvt_pk_f16_f32 (two values per
-// instruction); measured per value (tools/micro/wave_chain.hip, one wave per SIMD): 16 clk, against 24 for the form that ends in
-// v_fma_mix*_f16.
+// y -> (hi, lo) f16 planes:  hi = f16(y), lo = f16(y - hi), UNSCALED: v_mfma_f32_*_f16 honours f16 subnormals on gfx950
+// (tools/micro/mfma_f16_subnormal.hip: 2^-24 comes through exactly), so the residual needs no 2^12 lift to survive - its absolute
+// error is <= 2^-25 (subnormal spacing) or 2^-11 of itself, i.e. <= max(3e-8, 2^-22 |y|).  Every product term then carries the same
+// scale and ONE accumulator takes hi.hi + hi.lo + lo.hi: no join multiply-add per value, half the accumulator registers.
+// Pairs go through v_cvt_pk_f16_f32 (two values per instruction).
 typedef _Float16 v2h __attribute__((ext_vector_type(2)));
 typedef float v2f __attribute__((ext_vector_type(2)));
+__host__ __device__ inline void split_u(float x, h16 &h, h16 &l) { h = (h16)x; l = (h16)(x - (float)h); }
 template <int N>
 __device__ __forceinline__ void split_stage(const float (&y)[N], h16 (&h)[N], h16 (&l)[N]) {
     static_assert(N % 2 == 0, "pairs");
@@ -139,8 +140,6 @@ __device__ __forceinline__ void split_stage(const float (&y)[N], h16 (&h)[N], h1
     for (int i = 0; i < N; i += 2) { const v2h p = __builtin_convertvector((v2f){ y[i], y[i + 1] }, v2h); h[i] = p[0]; h[i + 1] = p[1]; }
 #pragma unroll
     for (int i = 0; i < N; ++i) d[i] = y[i] - (float)h[i];
-#pragma unroll
-    for (int i = 0; i < N; ++i) d[i] *= LO_SCALE;
 #pragma unroll
     for (int i = 0; i < N; i += 2) { const v2h p = __builtin_convertvector((v2f){ d[i], d[i + 1] }, v2h); l[i] = p[0]; l[i + 1] = p[1]; }
 }
@@ -153,27 +152,27 @@ template <int KB, int CT, bool TANH, bool BIAS>
 __device__ __forceinline__ void dense_act(const Frags<KB, CT> &f, const float *bias, const Act<KB> &x, Act<CT / 2> &y, v4f *keep, int lane) {
     const int g = lane >> 4;
     const v4f zero = (v4f){ 0.f, 0.f, 0.f, 0.f };
-    v4f hh[CT], cr[CT];
+    v4f acc[CT];
 #pragma unroll
     for (int p = 0; p <= CT / 2; ++p) {
         if (p < CT / 2) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int ct = 2 * p + t;
-                if (BIAS) { const float4 b = *reinterpret_cast<const float4 *>(bias + 16 * ct + 4 * g); hh[ct] = (v4f){ b.x, b.y, b.z, b.w }; }
+                if (BIAS) { const float4 b = *reinterpret_cast<const float4 *>(bias + 16 * ct + 4 * g); acc[ct] = (v4f){ b.x, b.y, b.z, b.w }; }
 #pragma unroll
                 for (int q = 0; q < KB; ++q) {
-                    const v4f h0 = (q == 0 && !BIAS) ? zero : hh[ct], c0 = q == 0 ? zero : cr[ct];
-                    hh[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.h[ct][q], x.hi[q], h0, 0, 0, 0);
-                    cr[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.h[ct][q], x.lo[q], c0, 0, 0, 0);
-                    cr[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.l[ct][q], x.hi[q], cr[ct], 0, 0, 0);
+                    const v4f a0 = (q == 0 && !BIAS) ? zero : acc[ct];
+                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.h[ct][q], x.lo[q], a0, 0, 0, 0);      // small terms first
+                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.l[ct][q], x.hi[q], acc[ct], 0, 0, 0);
+                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.h[ct][q], x.hi[q], acc[ct], 0, 0, 0);
                 }
             }
         }
         if (p > 0) {
             float v[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = fmaf(cr[2 * (p - 1) + (e >> 2)][e & 3], LO_INV, hh[2 * (p - 1) + (e >> 2)][e & 3]);
+            for (int e = 0; e < 8; ++e) v[e] = acc[2 * (p - 1) + (e >> 2)][e & 3];
             if (TANH) tanh_stage<8>(v);
             if (keep) {
 #pragma unroll
@@ -193,28 +192,24 @@ template <int KB, int CT, bool SWAP, bool BIAS>
 __device__ __forceinline__ void dense_f32(const Frags<KB, CT> &f, const float *bias, const Act<KB> &x, v4f (&out)[CT], int lane) {
     const int g = lane >> 4;
     const v4f zero = (v4f){ 0.f, 0.f, 0.f, 0.f };
-    v4f hh[CT], cr[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
-        if (BIAS) { const float4 b = *reinterpret_cast<const float4 *>(bias + 16 * ct + 4 * g); hh[ct] = (v4f){ b.x, b.y, b.z, b.w }; }
+        v4f acc = zero;
+        if (BIAS) { const float4 b = *reinterpret_cast<const float4 *>(bias + 16 * ct + 4 * g); acc = (v4f){ b.x, b.y, b.z, b.w }; }
 #pragma unroll
         for (int q = 0; q < KB; ++q) {
-            const v4f h0 = (q == 0 && !BIAS) ? zero : hh[ct], c0 = q == 0 ? zero : cr[ct];
             if (!SWAP) {
-                hh[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.h[ct][q], x.hi[q], h0, 0, 0, 0);
-                cr[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.h[ct][q], x.lo[q], c0, 0, 0, 0);
-                cr[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.l[ct][q], x.hi[q], cr[ct], 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.h[ct][q], x.lo[q], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.l[ct][q], x.hi[q], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.h[ct][q], x.hi[q], acc, 0, 0, 0);
             } else {
-                hh[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(x.hi[q], f.h[ct][q], h0, 0, 0, 0);
-                cr[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(x.lo[q], f.h[ct][q], c0, 0, 0, 0);
-                cr[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(x.hi[q], f.l[ct][q], cr[ct], 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(x.lo[q], f.h[ct][q], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(x.hi[q], f.l[ct][q], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(x.hi[q], f.h[ct][q], acc, 0, 0, 0);
             }
         }
+        out[ct] = acc;
     }
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) out[ct][r] = fmaf(cr[ct][r], LO_INV, hh[ct][r]);
 }
 
 #define CM_WPROBE(i) do { if (a.probe && tid == 0) a.probe[(size_t)blk * mf::NPROBE + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -299,12 +294,12 @@ __device__ __forceinline__ void policy_tile_w(const FwdArgs &a, int n_act, const
     {
         Act<2> xq;
         dense_act<2, 4, false, false>(f_at, nullptr, xe, xq, nullptr, lane);
-        v4f hh = (v4f){ 0.f, 0.f, 0.f, 0.f }, cr = hh;
+        v4f hh = (v4f){ 0.f, 0.f, 0.f, 0.f };
 #pragma unroll
-        for (int q = 0; q < 2; ++q) { CM_MFW(xe.hi[q], xq.hi[q], hh); CM_MFW(xe.hi[q], xq.lo[q], cr); CM_MFW(xe.lo[q], xq.hi[q], cr); }
+        for (int q = 0; q < 2; ++q) { CM_MFW(xe.hi[q], xq.lo[q], hh); CM_MFW(xe.lo[q], xq.hi[q], hh); CM_MFW(xe.hi[q], xq.hi[q], hh); }
         float sc[4], mx = -INFINITY, sum = 0.0f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { sc[r] = fmaf(cr[r], LO_INV, hh[r]); mx = fmaxf(mx, sc[r]); }
+        for (int r = 0; r < 4; ++r) { sc[r] = hh[r]; mx = fmaxf(mx, sc[r]); }
 #pragma unroll
         for (int r = 0; r < 4; ++r) { m[r] = __builtin_amdgcn_exp2f((sc[r] - mx) * 1.4426950408889634f); sum += m[r]; }
         const float rs = __builtin_amdgcn_rcpf(sum);
@@ -359,19 +354,19 @@ __device__ __forceinline__ void policy_tile_w(const FwdArgs &a, int n_act, const
 #pragma unroll
             for (int i = 0; i < 16; ++i) { ah[i >> 2][i & 3] = h[i]; al[i >> 2][i & 3] = lo_[i]; }
         }
-        v4f acc[4], cr[4];
+        v4f acc[4];
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
             const float4 b = *reinterpret_cast<const float4 *>(BL + bm.g + l * EMB + 16 * ct + 4 * g);
-            acc[ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah[ct], bh, (v4f){ b.x, b.y, b.z, b.w }, 0, 0, 0);
-            cr[ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah[ct], bl, (v4f){ 0.f, 0.f, 0.f, 0.f }, 0, 0, 0);
-            cr[ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(al[ct], bh, cr[ct], 0, 0, 0);
+            acc[ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah[ct], bl, (v4f){ b.x, b.y, b.z, b.w }, 0, 0, 0);
+            acc[ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(al[ct], bh, acc[ct], 0, 0, 0);
+            acc[ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah[ct], bh, acc[ct], 0, 0, 0);
         }
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             float v[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = fmaf(cr[2 * p + (e >> 2)][e & 3], LO_INV, acc[2 * p + (e >> 2)][e & 3]);
+            for (int e = 0; e < 8; ++e) v[e] = acc[2 * p + (e >> 2)][e & 3];
             tanh_stage<8>(v);                                             // graph_conv_module.py:65-70 (pre-activation prescaled)
             if (last && !a.no_residual) {
 #pragma unroll

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int it = 0; it < iters; ++it) {
         float w[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) w[e] = fmaf(v[e], LO_INV, accum);
+        for (int e = 0; e < 8; ++e) w[e] = fmaf(v[e], 0.000244140625f, accum);
         if (mode & 1) tanh_stage<8>(w);
         h16 h[8], l[8];
         if (mode & 2) {
