@@ -21,8 +21,14 @@ static __device__ unsigned long long g_w_probe[4];
 // phase's 16-lane groups are the wave's own envs - so no workgroup barrier exists after the one behind the weight staging, and
 // with n_steps > 1 the wave simply loops (weights stay where they are: LDS image + the register-resident 128 -> 64 layer).
 // LDS: [policy image | 64 actions | 16 env areas].
-template <int LHOPS, bool PRE, bool FULLWG>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rollout_w_kernel(mf::FwdArgs a, mw::WeightsW w, EnvDev p, cm_rng_tape tape, cm_step_out out, ChunkArgs c) {
+// Scalar registers are the scarce resource of this kernel (every kernel argument lives in SGPRs for the whole step loop; what does not
+// fit is spilled to VGPR lanes and comes back through v_readlane): the per-step strides travel as 32-bit element counts and the
+// RNG tape - test-only, single-step launches - is a compile-time variant.
+struct StridesW { int n_steps, obs, actions, probs, attn, reward, reward_f64, done, details, dist_adj, channels, prey_alive, success, path_len; };
+
+template <int LHOPS, bool PRE, bool FULLWG, bool TAPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rollout_w_kernel(mf::FwdArgs a, mw::WeightsW w, EnvDev p, cm_rng_tape tape_arg, cm_step_out out, StridesW c) {
+    const cm_rng_tape tape = TAPE ? tape_arg : cm_rng_tape{};
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_w[];
     constexpr int LPE = 16;
     constexpr int ACT_OFF = mw::pack_w(LHOPS).lds_u4 * 16, ENV_BASE = ACT_OFF + mw::WG_ROWS * 4;
@@ -42,13 +48,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const bool env_wave = FULLWG || (tx & ~63) / LPE < envs;        // a wave with an env of its own
         const int b_raw = blockIdx.x * mw::WG_ENVS + (live ? grp : 0);
         mf::FwdArgs at = a;
-        at.obs = a.obs + t * c.obs;
-        at.adj = a.adj ? a.adj + t * c.dist_adj : nullptr;
-        at.chan = a.chan ? a.chan + t * c.channels : nullptr;
+        at.obs = a.obs + (size_t)t * c.obs;
+        at.adj = a.adj ? a.adj + (size_t)t * c.dist_adj : nullptr;
+        at.chan = a.chan ? a.chan + (size_t)t * c.channels : nullptr;
         at.policy_step = a.policy_step + (uint32_t)t;
-        at.actions = a.actions ? a.actions + t * c.actions : nullptr;
-        at.probs = a.probs ? a.probs + t * c.probs : nullptr;
-        at.attn = a.attn ? a.attn + t * c.attn : nullptr;
+        at.actions = a.actions ? a.actions + (size_t)t * c.actions : nullptr;
+        at.probs = a.probs ? a.probs + (size_t)t * c.probs : nullptr;
+        at.attn = a.attn ? a.attn + (size_t)t * c.attn : nullptr;
         EnvPre pre{};
         const unsigned long long t0 = probe ? __builtin_amdgcn_s_memtime() : 0ull;
         if constexpr (PRE) pre = env_prefetch<CM_PP, LPE>(p, b_raw, live);   // env state requested in front of the policy forward
@@ -56,16 +62,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // this wave's action words are in LDS
         const unsigned long long t1 = probe ? __builtin_amdgcn_s_memtime() : 0ull;
         cm_step_out ot = out;
-        if (ot.obs) ot.obs += t * c.obs;
-        if (ot.reward) ot.reward += t * c.reward;
-        if (ot.reward_f64) ot.reward_f64 += t * c.reward_f64;
-        if (ot.done) ot.done += t * c.done;
-        if (ot.details) ot.details += t * c.details;
-        if (ot.dist_adj) ot.dist_adj += t * c.dist_adj;
-        if (ot.channels) ot.channels += t * c.channels;
-        if (ot.prey_alive) ot.prey_alive += t * c.prey_alive;
-        if (ot.success) ot.success += t * c.success;
-        if (ot.path_len) ot.path_len += t * c.path_len;
+        if (ot.obs) ot.obs += (size_t)t * c.obs;
+        if (ot.reward) ot.reward += (size_t)t * c.reward;
+        if (ot.reward_f64) ot.reward_f64 += (size_t)t * c.reward_f64;
+        if (ot.done) ot.done += (size_t)t * c.done;
+        if (ot.details) ot.details += (size_t)t * c.details;
+        if (ot.dist_adj) ot.dist_adj += (size_t)t * c.dist_adj;
+        if (ot.channels) ot.channels += (size_t)t * c.channels;
+        if (ot.prey_alive) ot.prey_alive += (size_t)t * c.prey_alive;
+        if (ot.success) ot.success += (size_t)t * c.success;
+        if (ot.path_len) ot.path_len += (size_t)t * c.path_len;
         if (env_wave) {
             const int32_t *my_act = act + (live ? grp : 0) * 4;
             if constexpr (PRE) {
@@ -92,22 +98,30 @@ int launch_rollout_w(mf::FwdArgs a, const cm_policy_weights *w, const void *w_pa
     const size_t lds = mw::lds_policy_bytes(d.L) + (size_t)d.lds_env * mw::WG_ENVS;
     if (lds > 160 * 1024) return 1;                                      // larger maps: the env areas do not fit beside the weights
     const mw::WeightsW ww{ reinterpret_cast<const uint4 *>(w_pack), w->n_act };
-    ChunkArgs c{};
+    StridesW c{};
     c.n_steps = 1;
-    if (chunk) c = *chunk;
+    if (chunk) {
+        const long long st[13] = { chunk->obs, chunk->actions, chunk->probs, chunk->attn, chunk->reward, chunk->reward_f64, chunk->done, chunk->details,
+                                   chunk->dist_adj, chunk->channels, chunk->prey_alive, chunk->success, chunk->path_len };
+        for (long long v : st) if (v < 0 || v > 0x7fffffffLL) return 1;   // strides beyond 2^31 elements: the workgroup-tiled kernels take it
+        c = StridesW{ chunk->n_steps, (int)st[0], (int)st[1], (int)st[2], (int)st[3], (int)st[4], (int)st[5], (int)st[6], (int)st[7], (int)st[8],
+                      (int)st[9], (int)st[10], (int)st[11], (int)st[12] };
+    }
+    const bool use_tape = t.prey || t.spawn || t.iid_u || t.ge_u || t.ge_init_u;
     const int blocks = (a.S + mw::WG_ENVS - 1) / mw::WG_ENVS;
     static const int pre_flag = [] { const char *e = getenv("COMMARL_ENV_PREFETCH"); return (e && e[0] == '0') ? 0 : 1; }();
     const bool pre = pre_flag && env_prefetch_ok<CM_PP, 16>(d), full = a.S % mw::WG_ENVS == 0;
-#define CM_RW(LH, PR, FU)                                                                                                       \
+#define CM_RW(LH, PR, FU, TP)                                                                                                   \
     do {                                                                                                                        \
         static unsigned long long done = 0;                                                                                     \
         if (cm::dev_first(done))                                                                                                \
-            CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_w_kernel<LH, PR, FU>),                           \
+            CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_w_kernel<LH, PR, FU, TP>),                       \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                                \
-        hipLaunchKernelGGL((rollout_w_kernel<LH, PR, FU>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, a, ww, d, t, out, c); \
+        hipLaunchKernelGGL((rollout_w_kernel<LH, PR, FU, TP>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, a, ww, d, t, out, c); \
     } while (0)
-#define CM_RW2(LH) do { if (pre) { if (full) CM_RW(LH, true, true); else CM_RW(LH, true, false); }                              \
-                        else { if (full) CM_RW(LH, false, true); else CM_RW(LH, false, false); } } while (0)
+#define CM_RW2(LH) do { if (use_tape) CM_RW(LH, false, false, true);                                                            \
+                        else if (pre) { if (full) CM_RW(LH, true, true, false); else CM_RW(LH, true, false, false); }           \
+                        else { if (full) CM_RW(LH, false, true, false); else CM_RW(LH, false, false, false); } } while (0)
     if (d.L == 1) CM_RW2(1); else CM_RW2(2);
 #undef CM_RW2
 #undef CM_RW
