@@ -11,6 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("COMMARL_LIB") or os.path.join(HERE, "libcommarl_hip.so")
 
 CM_PP, CM_CO = 0, 1
+PACK_F32, PACK_F16, PACK_WAVE, PACK_CHECK, PACK_ALL = 1, 2, 4, 8, 15      # cm_*_pack_sections (include/commarl.h)
 CHANNELS = {"FC": 0, "FL": 1, "IID": 2, "GE": 3}
 RNG_PHILOX, RNG_TAPE = 0, 1
 
@@ -102,6 +103,8 @@ _SIGNATURES = {
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(StepOut), C.c_void_p]),
     "cm_policy_pack_bytes": (C.c_size_t, [C.POINTER(PolicyWeights)]),
     "cm_policy_pack": (C.c_int, [C.POINTER(PolicyWeights), C.c_void_p, C.c_void_p]),
+    "cm_policy_pack_sections": (C.c_int, [C.POINTER(PolicyWeights), C.c_void_p, C.c_int32, C.c_void_p]),
+    "cm_critic_pack_sections": (C.c_int, [C.POINTER(CriticWeights), C.c_void_p, C.c_int32, C.c_void_p]),
     "cm_critic_pack_bytes": (C.c_size_t, [C.POINTER(CriticWeights)]),
     "cm_critic_pack": (C.c_int, [C.POINTER(CriticWeights), C.c_void_p, C.c_void_p]),
     "cm_mlp_policy_forward": (C.c_int, [C.POINTER(MlpWeights), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,

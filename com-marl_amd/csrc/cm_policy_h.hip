@@ -192,28 +192,31 @@ size_t policy_pack_h_bytes(int d, int L, bool policy) {
     return kh ? mh::pack_layout_h(kh, L, policy).total * sizeof(uint4) : 0;
 }
 
-int policy_pack_h(const cm_policy_weights *w, void *dst, void *stream) {
+int policy_pack_h(const cm_policy_weights *w, void *dst, int sections, void *stream) {
     const int kh = mh::kh_of(w->d);
     if (!kh) return CM_OK;                               // no f16 instantiation for this obs dim: nothing to pack
     const mh::PackLayoutH lo = mh::pack_layout_h(kh, w->n_hops, true);
     uint4 *pack = reinterpret_cast<uint4 *>(dst);
-    int *bad = mh::range_check_begin(stream);
-    if (int rc = mh::pack_trunk_h(w->d, w->n_hops, w->enc_w1t, w->enc_w2t, w->attn_wt, w->gcn_w, kh, lo, pack, stream, bad)) return rc;
-    if (int rc = mh::pack_one_h(w->hd_w1t, mf::EMB, mf::H1, mf::EMB, mf::H1, pack + lo.x1, stream, bad)) return rc;
-    if (int rc = mh::pack_one_h(w->hd_w2t, mf::H1, mf::H2, mf::H1, mf::H2, pack + lo.h2, stream, bad)) return rc;
-    if (int rc = mh::pack_one_h(w->hd_w3t, mf::H2, mf::H3, mf::H2, mf::H3, pack + lo.h3, stream, bad)) return rc;
-    if (int rc = mh::pack_one_h(w->hd_w4t, mf::H3, w->n_act, mf::H3, 16, pack + lo.h4, stream, bad)) return rc;
+    int *bad = (sections & CM_PACK_CHECK) ? mh::range_check_begin(stream) : nullptr;
+    if (sections & CM_PACK_F16) {
+        if (int rc = mh::pack_trunk_h(w->d, w->n_hops, w->enc_w1t, w->enc_w2t, w->attn_wt, w->gcn_w, kh, lo, pack, stream, bad)) return rc;
+        if (int rc = mh::pack_one_h(w->hd_w1t, mf::EMB, mf::H1, mf::EMB, mf::H1, pack + lo.x1, stream, bad)) return rc;
+        if (int rc = mh::pack_one_h(w->hd_w2t, mf::H1, mf::H2, mf::H1, mf::H2, pack + lo.h2, stream, bad)) return rc;
+        if (int rc = mh::pack_one_h(w->hd_w3t, mf::H2, mf::H3, mf::H2, mf::H3, pack + lo.h3, stream, bad)) return rc;
+        if (int rc = mh::pack_one_h(w->hd_w4t, mf::H3, w->n_act, mf::H3, 16, pack + lo.h4, stream, bad)) return rc;
+    }
     // teams of 4: the wave-owned kernel's fragments (another k order, cm_policy_w.hip), behind this section
-    if (int rc = policy_pack_w(w, reinterpret_cast<char *>(dst) + lo.total * sizeof(uint4), stream, bad)) return rc;
+    if (sections & CM_PACK_WAVE)
+        if (int rc = policy_pack_w(w, reinterpret_cast<char *>(dst) + lo.total * sizeof(uint4), stream, bad)) return rc;
     return mh::range_check_end(bad, stream, "cm_policy_pack");
 }
 
-int critic_pack_h(const cm_critic_weights *w, void *dst, void *stream) {
+int critic_pack_h(const cm_critic_weights *w, void *dst, int sections, void *stream) {
     const int kh = mh::kh_of(w->d);
-    if (!kh) return CM_OK;
+    if (!kh || !(sections & CM_PACK_F16)) return CM_OK;
     const mh::PackLayoutH lo = mh::pack_layout_h(kh, w->n_hops, false);
     uint4 *pack = reinterpret_cast<uint4 *>(dst);
-    int *bad = mh::range_check_begin(stream);
+    int *bad = (sections & CM_PACK_CHECK) ? mh::range_check_begin(stream) : nullptr;
     if (int rc = mh::pack_trunk_h(w->d, w->n_hops, w->enc_w1t, w->enc_w2t, w->attn_wt, w->gcn_w, kh, lo, pack, stream, bad)) return rc;
     if (int rc = mh::pack_one_h(w->dec_w1t, mf::EMB, mf::DH, mf::EMB, mf::DH, pack + lo.x1, stream, bad)) return rc;
     return mh::range_check_end(bad, stream, "cm_critic_pack");

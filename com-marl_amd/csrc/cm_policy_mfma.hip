@@ -146,8 +146,8 @@ static int pack_trunk(int d, int L, const float *w1t, const float *w2t, const fl
 // cm_policy_h.hip: the f16-split kernel (default) and its operand pack, stored BEHIND the f32 pack in the caller's buffer
 bool policy_h_enabled();
 size_t policy_pack_h_bytes(int d, int L, bool policy);
-int policy_pack_h(const cm_policy_weights *w, void *dst, void *stream);
-int critic_pack_h(const cm_critic_weights *w, void *dst, void *stream);
+int policy_pack_h(const cm_policy_weights *w, void *dst, int sections, void *stream);
+int critic_pack_h(const cm_critic_weights *w, void *dst, int sections, void *stream);
 int policy_forward_h(const cm_policy_weights *w, const void *h_pack, mf::FwdArgs a, void *stream);
 // cm_policy_w.hip: the wave-owned teams-of-4 kernel (default where the shape allows); its fragments sit behind the f16 pack
 size_t policy_pack_w_bytes(const cm_policy_weights *w);
@@ -254,18 +254,24 @@ extern "C" size_t cm_policy_pack_bytes(const cm_policy_weights *w) {
            cm::policy_pack_w_bytes(w);
 }
 
-extern "C" int cm_policy_pack(const cm_policy_weights *w, float *pack, void *stream) {
+extern "C" int cm_policy_pack_sections(const cm_policy_weights *w, float *pack, int32_t sections, void *stream) {
     using namespace cm;
     if (!w || !pack) return set_error(CM_ERR_ARG, "cm_policy_pack: null argument");
     if (!policy_shape_ok(w)) return set_error(CM_ERR_ARG, "cm_policy_pack: this shape has no matrix-core instantiation (cm_policy_pack_bytes() == 0)");
     const int kpad = mf::kpad_of(w->d);
     const mf::PackLayout lo = mf::pack_layout(kpad, w->n_hops, true);
-    if (int rc = mf::pack_trunk(w->d, w->n_hops, w->enc_w1t, w->enc_w2t, w->attn_wt, w->gcn_w, kpad, lo, pack, stream)) return rc;
-    if (int rc = mf::pack_one(w->hd_w1t, mf::EMB, mf::H1, mf::EMB, mf::H1, pack + lo.x1, stream)) return rc;
-    if (int rc = mf::pack_one(w->hd_w2t, mf::H1, mf::H2, mf::H1, mf::H2, pack + lo.h2, stream)) return rc;
-    if (int rc = mf::pack_one(w->hd_w3t, mf::H2, mf::H3, mf::H2, mf::H3, pack + lo.h3, stream)) return rc;
-    if (int rc = mf::pack_one(w->hd_w4t, mf::H3, w->n_act, mf::H3, 16, pack + lo.h4, stream)) return rc;
-    return policy_pack_h(w, pack + lo.total, stream);          // the f16 (hi, lo) fragments, behind the f32 ones
+    if (sections & CM_PACK_F32) {
+        if (int rc = mf::pack_trunk(w->d, w->n_hops, w->enc_w1t, w->enc_w2t, w->attn_wt, w->gcn_w, kpad, lo, pack, stream)) return rc;
+        if (int rc = mf::pack_one(w->hd_w1t, mf::EMB, mf::H1, mf::EMB, mf::H1, pack + lo.x1, stream)) return rc;
+        if (int rc = mf::pack_one(w->hd_w2t, mf::H1, mf::H2, mf::H1, mf::H2, pack + lo.h2, stream)) return rc;
+        if (int rc = mf::pack_one(w->hd_w3t, mf::H2, mf::H3, mf::H2, mf::H3, pack + lo.h3, stream)) return rc;
+        if (int rc = mf::pack_one(w->hd_w4t, mf::H3, w->n_act, mf::H3, 16, pack + lo.h4, stream)) return rc;
+    }
+    return policy_pack_h(w, pack + lo.total, sections, stream);   // the f16 (hi, lo) fragments (+ the wave-owned section), behind the f32 ones
+}
+
+extern "C" int cm_policy_pack(const cm_policy_weights *w, float *pack, void *stream) {
+    return cm_policy_pack_sections(w, pack, CM_PACK_ALL, stream);
 }
 
 extern "C" size_t cm_critic_pack_bytes(const cm_critic_weights *w) {
@@ -273,13 +279,19 @@ extern "C" size_t cm_critic_pack_bytes(const cm_critic_weights *w) {
     return cm::mf::pack_layout(cm::mf::kpad_of(w->d), w->n_hops, false).total * sizeof(float) + cm::policy_pack_h_bytes(w->d, w->n_hops, false);
 }
 
-extern "C" int cm_critic_pack(const cm_critic_weights *w, float *pack, void *stream) {
+extern "C" int cm_critic_pack_sections(const cm_critic_weights *w, float *pack, int32_t sections, void *stream) {
     using namespace cm;
     if (!w || !pack) return set_error(CM_ERR_ARG, "cm_critic_pack: null argument");
     if (!critic_shape_ok(w)) return set_error(CM_ERR_ARG, "cm_critic_pack: this shape has no matrix-core instantiation (cm_critic_pack_bytes() == 0)");
     const int kpad = mf::kpad_of(w->d);
     const mf::PackLayout lo = mf::pack_layout(kpad, w->n_hops, false);
-    if (int rc = mf::pack_trunk(w->d, w->n_hops, w->enc_w1t, w->enc_w2t, w->attn_wt, w->gcn_w, kpad, lo, pack, stream)) return rc;
-    if (int rc = mf::pack_one(w->dec_w1t, mf::EMB, mf::DH, mf::EMB, mf::DH, pack + lo.x1, stream)) return rc;
-    return critic_pack_h(w, pack + lo.total, stream);
+    if (sections & CM_PACK_F32) {
+        if (int rc = mf::pack_trunk(w->d, w->n_hops, w->enc_w1t, w->enc_w2t, w->attn_wt, w->gcn_w, kpad, lo, pack, stream)) return rc;
+        if (int rc = mf::pack_one(w->dec_w1t, mf::EMB, mf::DH, mf::EMB, mf::DH, pack + lo.x1, stream)) return rc;
+    }
+    return critic_pack_h(w, pack + lo.total, sections, stream);
+}
+
+extern "C" int cm_critic_pack(const cm_critic_weights *w, float *pack, void *stream) {
+    return cm_critic_pack_sections(w, pack, CM_PACK_ALL, stream);
 }

@@ -354,17 +354,21 @@ class _FusedNetFn(torch.autograd.Function):
             sv.hw[l], sv.h[l] = t["hw"][l].data_ptr(), t["h"][l].data_ptr()
         adj_c = None if adj is None else adj.contiguous()
         ch_c = None if ch is None else ch.contiguous()
-        with torch.cuda.device(dev):
-            if policy:
-                w = net._weights_struct()
-                rc = L.lib().cm_policy_forward_saved(C.byref(w), S, L.ptr(obs2), L.ptr(adj_c), L.ptr(ch_c), L.ptr(attn),
-                                                     C.byref(sv), L.current_stream())
-            else:
-                w = net._struct_from(net._packed())
-                w.mfma_pack = None if net._mfma is None else net._mfma.data_ptr()
-                vals = z(S)
-                rc = L.lib().cm_critic_forward_saved(C.byref(w), S, L.ptr(obs2), L.ptr(adj_c), L.ptr(ch_c), L.ptr(attn),
-                                                     L.ptr(vals), C.byref(sv), L.current_stream())
+        net._train_fwd = True                          # the weight pack refreshes the f16-split section only (_WeightPack._packed)
+        try:
+            with torch.cuda.device(dev):
+                if policy:
+                    w = net._weights_struct()
+                    rc = L.lib().cm_policy_forward_saved(C.byref(w), S, L.ptr(obs2), L.ptr(adj_c), L.ptr(ch_c), L.ptr(attn),
+                                                         C.byref(sv), L.current_stream())
+                else:
+                    w = net._struct_from(net._packed())
+                    w.mfma_pack = None if net._mfma is None else net._mfma.data_ptr()
+                    vals = z(S)
+                    rc = L.lib().cm_critic_forward_saved(C.byref(w), S, L.ptr(obs2), L.ptr(adj_c), L.ptr(ch_c), L.ptr(attn),
+                                                         L.ptr(vals), C.byref(sv), L.current_stream())
+        finally:
+            net._train_fwd = False
         if rc == 1:
             raise L.CommarlError("no saved-forward instantiation for this shape (caller should have checked _fused_train_ok)")
         L.check(rc, "cm_*_forward_saved")
@@ -494,7 +498,7 @@ def _as_dev(x, device):
 class _WeightPack:
     """Flat device copy of a net's (transposed) weights for the fused C-ABI kernels; subclasses list the
     tensors in ``_pack_tensors()``."""
-    _pack_sig, _pack = None, None
+    _pack_sig, _pack, _pack_stale, _train_fwd = None, None, False, False
 
     def _pack_tensors(self):
         raise NotImplementedError
@@ -504,7 +508,11 @@ class _WeightPack:
         changed (optimizer step / load_state_dict) the SAME buffer is rewritten in place, so device
         pointers - and any hipGraph that captured them - stay valid."""
         sig = tuple((p.data_ptr(), p._version) for p in self.parameters())
-        if sig == self._pack_sig:
+        # a training forward (_FusedNetFn sets _train_fwd around its launch) reads the f16-split fragments only: between two optimiser steps just that section is
+        # refreshed (cm_*_pack_sections); the rest goes stale and is packed - with the range check - by the next no-grad user
+        # (sync_weights() before a rollout, evaluate_nograd, act_device)
+        partial = self._train_fwd and os.environ.get("COMMARL_PACK_PARTIAL", "1") != "0"
+        if sig == self._pack_sig and (partial or not self._pack_stale):
             return self._pack[1]
         with torch.no_grad():
             ts = self._pack_tensors()
@@ -526,11 +534,11 @@ class _WeightPack:
                     o, n = offs[k]
                     buf[o:o + n].copy_(v.detach().to(torch.float32).reshape(-1))
             self._pack_sig = None                               # a refused pack (cm_*_pack: weight outside the f16 range) is retried
-            self._after_pack(self._pack[1])
-            self._pack_sig = sig
+            self._after_pack(self._pack[1], L.PACK_F16 if partial else L.PACK_ALL)
+            self._pack_sig, self._pack_stale = sig, partial
         return self._pack[1]
 
-    def _after_pack(self, ptrs):
+    def _after_pack(self, ptrs, sections=15):
         """Hook: derived device-side layouts (the matrix-core operand pack) are rebuilt here."""
 
     def sync_weights(self):
@@ -627,9 +635,9 @@ class CommBaseNet(_WeightPack, nn.Module):
         ts.update(self._head_tensors())
         return ts
 
-    def _after_pack(self, ptrs):
-        """(Re)build the matrix-core operand pack (cm_policy_pack / cm_critic_pack) in its own persistent buffer:
-        same address for the life of the net, so captured hipGraphs keep reading fresh weights."""
+    def _after_pack(self, ptrs, sections=15):
+        """(Re)build the matrix-core operand pack (cm_policy_pack / cm_critic_pack; `sections`: which parts) in its own
+        persistent buffer: same address for the life of the net, so captured hipGraphs keep reading fresh weights."""
         dev = next(self.parameters()).device
         if dev.type != "cuda":
             return
@@ -640,7 +648,7 @@ class CommBaseNet(_WeightPack, nn.Module):
             self._mfma = torch.zeros(nbytes // 4, dtype=torch.float32, device=dev) if nbytes else None
         if self._mfma is not None:
             with torch.cuda.device(dev):
-                L.check(pack_fn(C.byref(w), L.ptr(self._mfma), L.current_stream()), self._mfma_fns[1])
+                L.check(pack_fn(C.byref(w), L.ptr(self._mfma), int(sections), L.current_stream()), self._mfma_fns[1])
 
 
 # ---------------------------------------------------------------------------------------------
@@ -751,7 +759,7 @@ class CommCategoricalMLPPolicy(CommBaseNet):
         w.mfma_pack = None if self._mfma is None else self._mfma.data_ptr()
         return w
 
-    _mfma, _mfma_fns = None, ("cm_policy_pack_bytes", "cm_policy_pack")
+    _mfma, _mfma_fns = None, ("cm_policy_pack_bytes", "cm_policy_pack_sections")
 
     def set_rng(self, seed, env_id_offset=0):
         """Philox stream of the action sampler: counter (env id, policy step, site 7, agent)."""
@@ -914,7 +922,7 @@ class CommBaseCritic(CommBaseNet):
         return OrderedDict(dec_w1t=m._layers[0].linear.weight.t(), dec_b1=m._layers[0].linear.bias,
                            dec_w2t=m._output_layers[0].linear.weight.t(), dec_b2=m._output_layers[0].linear.bias)
 
-    _mfma, _mfma_fns = None, ("cm_critic_pack_bytes", "cm_critic_pack")
+    _mfma, _mfma_fns = None, ("cm_critic_pack_bytes", "cm_critic_pack_sections")
 
     def _struct_from(self, p):
         w = L.CriticWeights()
@@ -999,7 +1007,7 @@ class _RowMLPPolicy(_WeightPack):
 
     _mlp_pack = None
 
-    def _after_pack(self, ptrs):
+    def _after_pack(self, ptrs, sections=15):
         """(Re)build the B-fragment pack of the chain (cm_mlp_pack) in a persistent buffer."""
         dev = next(self.parameters()).device
         if dev.type != "cuda":

@@ -196,8 +196,20 @@ typedef struct cm_critic_weights {
  * foreign caller's |obs| > 65504 saturates the same way and is NOT checked per step. */
 size_t cm_policy_pack_bytes(const cm_policy_weights *w);
 int cm_policy_pack(const cm_policy_weights *w, float *pack, void *stream);
+/* The pack has sections - the all-f32 fragments (COMMARL_POLICY_KERNEL=f32, shapes without an f16 instantiation), the f16-split
+ * fragments (every default kernel incl. the training forward), the wave-owned rollout kernel's fragments (teams of 4) - and a
+ * caller that knows its next consumer may refresh only what that consumer reads: an optimiser step followed by a training
+ * forward needs CM_PACK_F16 alone (10 launches and no wait instead of ~30 and one), the next rollout CM_PACK_ALL.
+ * cm_policy_pack / cm_critic_pack = CM_PACK_ALL.  A section that was skipped is STALE until a later call packs it. */
+#define CM_PACK_F32 1
+#define CM_PACK_F16 2
+#define CM_PACK_WAVE 4
+#define CM_PACK_CHECK 8           /* the f16 range check (waits for the pack kernels) */
+#define CM_PACK_ALL 15
+int cm_policy_pack_sections(const cm_policy_weights *w, float *pack, int32_t sections, void *stream);
 size_t cm_critic_pack_bytes(const cm_critic_weights *w);
 int cm_critic_pack(const cm_critic_weights *w, float *pack, void *stream);
+int cm_critic_pack_sections(const cm_critic_weights *w, float *pack, int32_t sections, void *stream);
 
 /* CommCategoricalMLPPolicy.get_actions (comm_categorical_mlp_policy.py:98-119) for S env
  * states in one fused launch: encoder -> attention -> L x (mask, renorm, GCN) -> residual ->
