@@ -12,31 +12,37 @@ SHAPES = {
     # every workgroup full (a multiple of 8 envs): the constant-shape build with the env state prefetched in front of
     # the policy forward (rollout_step_kernel<..., FULL, PRE>, cm_fused.hip)
     "pp_map10_full": ("pp", 10, 1, 4, 4, 2, 0.0, 208, 40, 9),
+    # one GCN hop, no skip connection, range adjacency + IID loss (masks read by the wave-owned kernel), 5 preys; ragged batch
+    "pp_map10_hop1": ("pp", 10, 1, 4, 5, 2, 0.3, 77, 24, 7),
     "co_map20": ("co", 20, 2, 24, 0, 2, 0.0, 7, 14, 6),
     "pp_map30": ("pp", 30, 2, 72, 72, 4, 0.0, 3, 8, 5),
     "co_map30_iid": ("co", 30, 2, 54, 0, 2, 0.3, 3, 8, 5),
 }
 
 
-def _params(scen, map_, sen, N, M, load, loss, mpl):
+def _hops(shape):
+    return 1 if shape.endswith("hop1") else 2
+
+
+def _params(scen, map_, sen, N, M, load, loss, mpl, hops=2):
     pp = scen == "pp"
     return dict(load=load, max_env_steps=mpl, capture_reward=10 if pp else 2, step_cost=0.1 if pp else 0, rm=0,
                 penalty=0 if pp else 1, revisit_penalty=0.5, lazy_penalty=1, grid_size=map_, Rsen=sen, n_agents=N,
-                n_preys=M, n_gcn_layers=2, mode="train", trRcom=9, trpl=loss, obstComplex="Easy", add_clock=0)
+                n_preys=M, n_gcn_layers=hops, mode="train", trRcom=9 if hops == 2 else 3, trpl=loss, obstComplex="Easy", add_clock=0)
 
 
 def _run(torch, shape, fused, greedy, chunked=False, faults=False):
     from com_marl_amd import envs as E, nets
     from com_marl_amd.rollout import RolloutEngine
     scen, map_, sen, N, M, load, loss, B, steps, mpl = SHAPES[shape]
-    env = E.GridEnvBatch(scen, _params(scen, map_, sen, N, M, load, loss, mpl), B, device="cuda:0", seed=3,
+    env = E.GridEnvBatch(scen, _params(scen, map_, sen, N, M, load, loss, mpl, _hops(shape)), B, device="cuda:0", seed=3,
                          max_steps=mpl if scen == "pp" else 400, max_path_length=mpl, env_id_offset=11)
     if faults:           # some agents cannot move (predator_prey.py:257-261): their condition travels with the prefetch
         env.apply_agent_fault("iid", 0.35, fault_step=2)
         assert 0 < env.agent_condition.mean() < 1
     spec = E.EnvSpec(E._Box(np.zeros(env.d * N), np.ones(env.d * N)), E._Discrete(5))
     torch.manual_seed(3)
-    pol = nets.CommCategoricalMLPPolicy(spec, n_agents=N, device="cuda:0")
+    pol = nets.CommCategoricalMLPPolicy(spec, n_agents=N, n_gcn_layers=_hops(shape), residual=_hops(shape) == 2, device="cuda:0")
     pol.set_rng(3)
     eng = RolloutEngine(env, pol, steps, fused=fused)
     eng.reset()
