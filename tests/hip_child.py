@@ -22,6 +22,8 @@ CASES = {
     "env_small_off": (dict(COMMARL_ENV_SMALL="0"), "occupancy-tile walk kept for small PP teams (the A/B of pp_small_step)"),
     "debug_library_env_goldens": (dict(COMMARL_LIB=os.path.join(ROOT, "com-marl_amd", "libcommarl_hip_dbg.so")),
                                   "range-checked (-DCM_BOUNDS) build: env goldens + Philox lock-step"),
+    "bench_two_rank_rehearsal": (dict(COMMARL_DIST_BACKEND="gloo"),
+                                 "bench.py --gpus 2 started without a launcher (self-launch), two gloo ranks on GPU 0: weak and --scaling strong"),
     "two_rank_train_once": ({}, "CentralizedMAPPO.train_once on 2 gloo ranks (both on GPU 0) == 1 process on the union (2 clipped steps; 5 steps without the ratio clip)"),
 }
 
@@ -82,6 +84,30 @@ def debug_library_env_goldens():
                     channel="GE"), 20)
     n += _lock(dict(scenario="pp", n_envs=40, n_agents=72, n_preys=72, grid=30, rsen=2, load=4, max_steps=9), 20)
     return dict(fixtures=len(ENV_FIXTURES), dones=n, lib=os.path.basename(L.LIB_PATH))
+
+
+def bench_two_rank_rehearsal():
+    """`python bench.py --gpus 2` with no launcher: bench.py starts its two ranks itself (torch.distributed.run, before anything touched
+    the GPU), they rendezvous over gloo on ONE card, run the sharded rollout + the train loop with the gradient all-reduce, and
+    rank 0 prints the contract line - marked as a rehearsal, not an N-GPU measurement."""
+    import subprocess
+    out = {}
+    for scaling in ("weak", "strong"):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "24", "--warmup", "4", "--envs", "512",
+               "--no-cpu-baseline", "--scaling", scaling]
+        p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=dict(os.environ, COMMARL_DIST_BACKEND="gloo"))
+        assert p.returncode == 0, p.stderr[-2000:]
+        line = [ln for ln in p.stdout.strip().splitlines() if ln.startswith("{")][-1]
+        d = json.loads(line)
+        per_gpu = 512 if scaling == "weak" else 256
+        assert d["rehearsal"] is True and d["ranks"] == 2 and d["n_gpus"] == 1 and d["backend"] == "gloo", d
+        assert d["scaling"] == scaling and d["config"]["envs_per_gpu"] == per_gpu and d["config"]["total_envs"] == 2 * per_gpu
+        assert d["value"] > 0 and d["steps"] == 24 and d["config"]["graphs"]["capture_in_timed_region"] is False
+        tl = d["train_loop"]
+        assert tl and "error" not in tl and tl["value"] > 0 and "all-reduce" in tl["schedule"], tl
+        assert "cpu_baseline" not in d and "configs" not in d                   # single-GPU extras stay out of multi-rank lines
+        out[scaling] = dict(value=d["value"], train_loop=tl["value"])
+    return out
 
 
 def two_rank_train_once():

@@ -212,3 +212,14 @@ def test_two_rank_train_once_equals_one_process_on_the_union():
     assert res["rc"] == 0, f"two-rank case failed:\n{res['tail']}"
     rep = res["report"]
     assert rep.get("ok") is True and rep["max_param_diff"] <= 2e-6 and rep["n_paths"][0] != rep["n_paths"][1], rep
+
+
+def test_bench_two_rank_rehearsal_line():
+    """bench.py's N > 1 branch end to end (self-launch, env sharding by global id, max-over-ranks timing, train loop with the
+    gradient all-reduce), weak and strong scaling, as two gloo ranks on the one card of this box: the line says `rehearsal`
+    and counts ONE GPU (tests/hip_child.py::bench_two_rank_rehearsal)."""
+    from tests.conftest import child_result
+    res = child_result("bench_two_rank_rehearsal")
+    assert res["rc"] == 0, f"two-rank bench rehearsal failed:\n{res['tail']}"
+    rep = res["report"]
+    assert rep.get("ok") is True and rep["weak"]["value"] > 0 and rep["strong"]["value"] > 0, rep
