@@ -763,6 +763,42 @@ static bool quad_bwd_on() {
 
 using namespace cm;
 
+// ---------------------------------------------------------------------------------------------------------------
+// The flat weight copy of a net (transposed [in,out] matrices + biases, what the C-ABI weight structs point into) in ONE
+// launch: tensor k is a [rows, cols] row-major source written to dst[k] as its TRANSPOSE ([cols, rows]) when transpose[k], else
+// copied as it is.  (The framework's per-tensor copy_ cost 17 launches per net and optimiser step.)
+// ---------------------------------------------------------------------------------------------------------------
+struct CopyTable { const float *src[40]; float *dst[40]; int rows[40], cols[40], transpose[40]; int count; };
+
+__global__ __launch_bounds__(256) void multi_copy_t_kernel(CopyTable t) {
+    const long stride = (long)gridDim.x * blockDim.x, i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int k = 0; k < t.count; ++k) {
+        const int R = t.rows[k], C = t.cols[k];
+        const long n = (long)R * C;
+        if (t.transpose[k]) {
+            for (long i = i0; i < n; i += stride) { const int c = (int)(i / R), r = (int)(i - (long)c * R); t.dst[k][i] = t.src[k][(long)r * C + c]; }   // dst [C][R]
+        } else {
+            for (long i = i0; i < n; i += stride) t.dst[k][i] = t.src[k][i];
+        }
+    }
+}
+
+extern "C" int cm_multi_copy_t(int32_t n, const float *const *src, float *const *dst, const int32_t *rows, const int32_t *cols,
+                               const int32_t *transpose, void *stream) {
+    if (n < 0 || n > 40) return set_error(CM_ERR_ARG, "cm_multi_copy_t: at most 40 tensors per call");
+    if (n == 0) return CM_OK;
+    if (!src || !dst || !rows || !cols || !transpose) return set_error(CM_ERR_ARG, "cm_multi_copy_t: null argument");
+    CopyTable t{};
+    t.count = n;
+    for (int k = 0; k < n; ++k) {
+        if (!src[k] || !dst[k] || rows[k] < 1 || cols[k] < 1) return set_error(CM_ERR_ARG, "cm_multi_copy_t: bad tensor");
+        t.src[k] = src[k]; t.dst[k] = dst[k]; t.rows[k] = rows[k]; t.cols[k] = cols[k]; t.transpose[k] = transpose[k];
+    }
+    hipLaunchKernelGGL(multi_copy_t_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, t);
+    CM_HIP(hipGetLastError());
+    return CM_OK;
+}
+
 extern "C" int cm_multi_adam_step(int32_t n, float *const *params, float *const *grads, float *const *exp_avg, float *const *exp_avg_sq,
                                   const int64_t *sizes, float *norm_ws, float max_norm, float lr, float beta1,
                                   float beta2, float eps, int32_t step, void *stream) {

@@ -295,14 +295,34 @@ def masked_aggregate(attn, dist_adj, channels, hop, hw, bias):
 # whole-network training forward (every team size <= 128): ONE fused launch that stores what the backward needs, and a hand-written
 # backward chain over the C-ABI kernels - no per-layer forward kernels, no gradient-accumulation adds from autograd
 # ---------------------------------------------------------------------------------------------
-def _lin_bwd(x2, w, layout, dy2, y2, want_dx, has_bias, dy_add=None):
+class _ZeroPool:
+    """The weight / bias gradients of one backward pass as views of ONE zero-filled buffer (one fill launch instead of one per
+    tensor; the kernels accumulate into them with float atomics, so they must start at zero).  Views are 16-byte aligned."""
+
+    def __init__(self, params, device):
+        total = sum((p.numel() + 3) & ~3 for p in params)
+        self.buf = torch.zeros(total, dtype=torch.float32, device=device)
+        self.off = 0
+
+    def take(self, shape):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        if self.off + n > self.buf.numel():                        # (not reached: sized from the net's parameter list)
+            return torch.zeros(*shape, dtype=torch.float32, device=self.buf.device)
+        v = self.buf[self.off:self.off + n].view(*shape)
+        self.off += (n + 3) & ~3
+        return v
+
+
+def _lin_bwd(x2, w, layout, dy2, y2, want_dx, has_bias, dy_add=None, pool=None):
     """cm_linear_act_backward on 2-D contiguous tensors -> (dx | None, dw, db | None); dy_add: a second gradient into the
-    layer's output, summed inside the kernel."""
+    layer's output, summed inside the kernel; pool: a _ZeroPool the weight / bias gradients are taken from."""
     R, K = x2.shape
     O = dy2.shape[1]
     dx = torch.empty_like(x2) if want_dx else None
-    dw = torch.zeros_like(w)
-    db = torch.zeros(O, dtype=torch.float32, device=w.device) if has_bias else None
+    dw = pool.take(w.shape) if pool is not None else torch.zeros_like(w)
+    db = (pool.take((O,)) if pool is not None else torch.zeros(O, dtype=torch.float32, device=w.device)) if has_bias else None
     with torch.cuda.device(w.device):
         L.check(L.lib().cm_linear_act_backward(R, K, O, L.ptr(x2), L.ptr(w), layout, L.ptr(dy2), L.ptr(dy_add), L.ptr(y2), L.ptr(dx),
                                                L.ptr(dw), L.ptr(db), L.current_stream()), "cm_linear_act_backward")
@@ -386,6 +406,7 @@ class _FusedNetFn(torch.autograd.Function):
         S = R // N
         P = dict(net.named_parameters())
         g = {}
+        pool = _ZeroPool(list(P.values()), obs2.device)
         if ctx.policy:
             hd = net.categorical_output_layer
             lins = [l.linear for l in hd._layers] + [hd._output_layers[0].linear]
@@ -394,14 +415,14 @@ class _FusedNetFn(torch.autograd.Function):
             d = d_out.reshape(R, -1).contiguous()
             for i in (3, 2, 1, 0):                                       # y of layer i = input of layer i + 1 (tanh), none for the logits
                 d, g[pre[i] + ".weight"], g[pre[i] + ".bias"] = _lin_bwd(acts[i], lins[i].weight, 0, d, None if i == 3 else acts[i + 1],
-                                                                          True, True)
+                                                                          True, True, pool=pool)
         else:
             mm = net.baseline_aggregator._mean_module
             l1, l2 = mm._layers[0].linear, mm._output_layers[0].linear
             pre = "baseline_aggregator._mean_module."
             d = d_out.reshape(R, 1).contiguous()
-            d, g[pre + "_output_layers.0.linear.weight"], g[pre + "_output_layers.0.linear.bias"] = _lin_bwd(t["x1"], l2.weight, 0, d, None, True, True)
-            d, g[pre + "_layers.0.linear.weight"], g[pre + "_layers.0.linear.bias"] = _lin_bwd(t["h"][Lh - 1], l1.weight, 0, d, t["x1"], True, True)
+            d, g[pre + "_output_layers.0.linear.weight"], g[pre + "_output_layers.0.linear.bias"] = _lin_bwd(t["x1"], l2.weight, 0, d, None, True, True, pool=pool)
+            d, g[pre + "_layers.0.linear.weight"], g[pre + "_layers.0.linear.bias"] = _lin_bwd(t["h"][Lh - 1], l1.weight, 0, d, t["x1"], True, True, pool=pool)
         # d = gradient wrt the trunk output x = E + H_L (or H_L)
         e, q = t["e"], t["q"]
         d_res = d if net.residual else None                              # residual: the same gradient flows into E
@@ -411,7 +432,7 @@ class _FusedNetFn(torch.autograd.Function):
                 gl = net.gcn_layers[l]
                 minus = e if (l == Lh - 1 and net.residual) else None       # saved x = E + H_L: the hop's tanh output is x - E
                 da, dhw = torch.empty_like(attn), torch.empty_like(e)
-                dgb = torch.zeros(64, dtype=torch.float32, device=e.device) if gl.bias is not None else None
+                dgb = pool.take((64,)) if gl.bias is not None else None
                 chan_ptr, stride = None, 0
                 if ch is not None:
                     chan_ptr, stride = ch.data_ptr() + 4 * l * N * N, ch.shape[1] * N * N
@@ -420,7 +441,7 @@ class _FusedNetFn(torch.autograd.Function):
                                                        L.current_stream()), "cm_masked_agg_backward")
                 d_attn = da if d_attn is None else d_attn.add_(da)
                 hin = t["h"][l - 1] if l > 0 else e
-                dhin, g["gcn_layers.%d.weight" % l], _ = _lin_bwd(hin, gl.weight, 1, dhw, None, True, False)
+                dhin, g["gcn_layers.%d.weight" % l], _ = _lin_bwd(hin, gl.weight, 1, dhw, None, True, False, pool=pool)
                 if gl.bias is not None:
                     g["gcn_layers.%d.bias" % l] = dgb
                 if l > 0:
@@ -435,19 +456,19 @@ class _FusedNetFn(torch.autograd.Function):
             L.check(L.lib().cm_attention_backward(S, N, 64, L.ptr(q), L.ptr(e), L.ptr(attn), L.ptr(d_attn), L.ptr(d_res), L.ptr(dhin0),
                                                   L.ptr(dq), L.ptr(dE), L.current_stream()), "cm_attention_backward")
         if net.attention_layer.attention_type == "general":
-            deq, g["attention_layer.linear_in.weight"], _ = _lin_bwd(e, net.attention_layer.linear_in.weight, 0, dq, None, True, False)
+            deq, g["attention_layer.linear_in.weight"], _ = _lin_bwd(e, net.attention_layer.linear_in.weight, 0, dq, None, True, False, pool=pool)
         else:
             deq = dq                                                     # 'dot': Q is E itself
         enc1, enc2 = net.encoder._layers[0].linear, net.encoder._output_layers[0].linear
         # both encoder layers in one pass (the gradient wrt the hidden layer never leaves the workgroup); wide observations
         # (d > 64) take the two layers one by one
-        dw2, db2 = torch.zeros_like(enc2.weight), torch.zeros_like(enc2.bias)
-        dw1, db1 = torch.zeros_like(enc1.weight), torch.zeros_like(enc1.bias)
+        dw2, db2 = pool.take(enc2.weight.shape), pool.take(enc2.bias.shape)
+        dw1, db1 = pool.take(enc1.weight.shape), pool.take(enc1.bias.shape)
         with torch.cuda.device(obs2.device):
             rc = L.lib().cm_encoder_backward(R, obs2.shape[1], L.ptr(obs2), L.ptr(t["a1"]), L.ptr(e), L.ptr(enc2.weight), L.ptr(dE), L.ptr(deq),
                                              L.ptr(dw2), L.ptr(db2), L.ptr(dw1), L.ptr(db1), L.current_stream())
         if rc == 1:
-            da1, dw2, db2 = _lin_bwd(t["a1"], enc2.weight, 0, dE, e, True, True, dy_add=deq)
+            da1, dw2, db2 = _lin_bwd(t["a1"], enc2.weight, 0, dE, e, True, True, dy_add=deq)     # (dw2 .. db1 taken above stay zero, unused)
             _, dw1, db1 = _lin_bwd(obs2, enc1.weight, 0, da1, t["a1"], False, True)
         else:
             L.check(rc, "cm_encoder_backward")
@@ -529,14 +550,41 @@ class _WeightPack:
                 ptrs = {k: (None if o is None else base + 4 * o[0]) for k, o in offs.items()}
                 self._pack = (buf, ptrs, offs)
             buf, ptrs, offs = self._pack
-            for k, v in ts.items():
-                if v is not None:
-                    o, n = offs[k]
-                    buf[o:o + n].copy_(v.detach().to(torch.float32).reshape(-1))
+            self._flat_copy(ts, buf, offs)
             self._pack_sig = None                               # a refused pack (cm_*_pack: weight outside the f16 range) is retried
             self._after_pack(self._pack[1], L.PACK_F16 if partial else L.PACK_ALL)
             self._pack_sig, self._pack_stale = sig, partial
         return self._pack[1]
+
+    def _flat_copy(self, ts, buf, offs):
+        """Every tensor of `ts` into its slot of the flat buffer.  On the GPU: ONE launch (cm_multi_copy_t) for all the plain
+        parameters and transposed weight views (`weight.t()`: the source is the parameter itself, the kernel transposes); anything
+        else (stacked GCN weights, ...) through the framework's copy."""
+        plain = []
+        for k, v in ts.items():
+            if v is None:
+                continue
+            o, n = offs[k]
+            dst = buf[o:o + n]
+            base = v._base if (v.dim() == 2 and v._base is not None and not v.is_contiguous()) else None
+            if (buf.is_cuda and v.dtype == torch.float32 and v.dim() <= 2 and len(plain) < 40
+                    and (v.is_contiguous() or (base is not None and base.is_contiguous() and base.dim() == 2
+                                               and base.shape == v.shape[::-1] and v.data_ptr() == base.data_ptr()))):
+                if v.is_contiguous():
+                    plain.append((v.data_ptr(), dst.data_ptr(), 1, n, 0))
+                else:                                        # v = base.t(): dst[c][r] = base[r][c]
+                    plain.append((base.data_ptr(), dst.data_ptr(), base.shape[0], base.shape[1], 1))
+            else:
+                dst.copy_(v.detach().to(torch.float32).reshape(-1))
+        if plain:
+            m = len(plain)
+            src = (C.c_void_p * m)(*[t[0] for t in plain])
+            dstp = (C.c_void_p * m)(*[t[1] for t in plain])
+            rows = (C.c_int32 * m)(*[t[2] for t in plain])
+            cols = (C.c_int32 * m)(*[t[3] for t in plain])
+            tr = (C.c_int32 * m)(*[t[4] for t in plain])
+            with torch.cuda.device(buf.device):
+                L.check(L.lib().cm_multi_copy_t(m, src, dstp, rows, cols, tr, L.current_stream()), "cm_multi_copy_t")
 
     def _after_pack(self, ptrs, sections=15):
         """Hook: derived device-side layouts (the matrix-core operand pack) are rebuilt here."""

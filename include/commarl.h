@@ -367,6 +367,11 @@ int cm_linear_act_backward(int64_t R, int32_t in_dim, int32_t out_dim, const flo
 int cm_encoder_backward(int64_t R, int32_t d, const float *obs, const float *a1, const float *e, const float *w2, const float *dy,
                         const float *dy2, float *dw2, float *db2, float *dw1, float *db1, void *stream);
 
+/* n tensors in one launch: src[k] is [rows[k], cols[k]] row-major f32; dst[k] receives its transpose ([cols, rows]) when
+ * transpose[k] != 0, else a plain copy.  The veneer refreshes a net's flat [in,out] weight copy with it (one launch instead of
+ * one framework copy per tensor).  n <= 40. */
+int cm_multi_copy_t(int32_t n, const float *const *src, float *const *dst, const int32_t *rows, const int32_t *cols,
+                    const int32_t *transpose, void *stream);
 /* Multi-tensor Adam step with optional gradient-norm clip, two launches for a whole net (csrc/cm_ppo.hip): the vendored
  * torch-1.9 Adam of the reference (com_marl/torch/algos/my_optimizer/_functional.py:72-98, no weight decay / amsgrad) preceded
  * - when norm_ws != NULL - by torch.nn.utils.clip_grad_norm_(params, max_norm) (centralized_ma_ppo.py:253-255), the clipped
