@@ -1,9 +1,10 @@
 // cm_policy_h_dev.h - fused Comm-DP policy / critic forward with the dense per-agent layers on the gfx950 f16 matrix
 // pipe, at f32 accuracy: every operand x is carried as TWO f16 planes
-//        hi = f16(x)              lo = f16((x - hi) * 2^12)            x = hi + 2^-12 lo  (error <= 2^-22 |x|)
-// and a 16x16x32 block of a product costs THREE v_mfma_f32_16x16x32_f16 (hi.hi, hi.lo, lo.hi; the cross terms have
-// their own accumulators and are scaled by 2^-12 once, in the epilogue; the dropped lo.lo term is 2^-24 relative)
-// instead of EIGHT v_mfma_f32_16x16x4_f32.  Measured on MI355X (tools/micro/layer_split_schemes.hip, 32 rows x 128 -> 64,
+//        hi = f16(x)              lo = f16(x - hi)            x = hi + lo  (error <= max(2^-22 |x|, 2^-25))
+// and a 16x16x32 block of a product costs THREE v_mfma_f32_16x16x32_f16 (hi.lo, lo.hi, hi.hi into ONE accumulator; the dropped
+// lo.lo term is 2^-22 relative) instead of EIGHT v_mfma_f32_16x16x4_f32.  (Rounds 1-2 stored lo scaled by 2^12 with the cross
+// terms in accumulators of their own, joined by a multiply-add per value; round 3 found the f16 MFMA honours subnormals - see
+// split2 below.)  Measured on MI355X for the scaled form (tools/micro/layer_split_schemes.hip, 32 rows x 128 -> 64,
 // tanh, chained layers, two workgroups per CU): 1871 clk per layer against 3678, max |error| against an f64 reference
 // 3.4e-7 against 7.0e-7 for the f32 MFMA form (the f16 instruction accumulates its 32 products more accurately than a
 // chain of eight f32 MFMAs does) - far inside the 1e-5 parity bar, and pinned by the reference fixtures.
@@ -38,22 +39,19 @@ typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef _Float16 v4h __attribute__((ext_vector_type(4)));
 typedef _Float16 h16;
 
-constexpr float LO_SCALE = 4096.0f, LO_INV = 1.0f / 4096.0f;
 constexpr int SHP = 8;                                  // halves of padding per plane row
 constexpr int SF = 68;                                  // f32 row stride (words) of the 64-wide f32 tiles (as mf::SE)
 
-#ifndef CM_H_VARIANT
-#define CM_H_VARIANT 0          // experiment bits: 1 = cross terms share one accumulator, 2 = residual as one fma
-#endif
+// Round 3: the lo plane is stored UNSCALED, lo = f16(x - hi).  v_mfma_f32_*_f16 honours f16 subnormals on gfx950
+// (tools/micro/mfma_f16_subnormal.hip: 2^-24 comes through exactly), so the residual needs no 2^12 lift to survive: its
+// absolute error is <= 2^-25 (subnormal spacing) or 2^-11 of itself, i.e. <= max(3e-8, 2^-22 |x|).  Every product term then has the
+// same scale and ONE accumulator takes hi.lo + lo.hi + hi.hi (small terms first): no join multiply-add per value, a third of the
+// accumulator registers, one multiply less per split.
 __host__ __device__ inline void split2(float x, h16 &h, h16 &l) {
     h = (h16)x;
-#if (CM_H_VARIANT & 2)
-    l = (h16)fmaf(-(float)h, LO_SCALE, x * LO_SCALE);   // exact: both products are exact, so is their difference
-#else
-    l = (h16)((x - (float)h) * LO_SCALE);
-#endif
+    l = (h16)(x - (float)h);
 }
-__device__ __forceinline__ float join2(h16 h, h16 l) { return fmaf((float)l, LO_INV, (float)h); }
+__device__ __forceinline__ float join2(h16 h, h16 l) { return (float)h + (float)l; }
 
 // A pair of f16 planes [rows][stride halves] in LDS
 struct Planes {
@@ -131,54 +129,31 @@ struct LayerH {
             v8h xh0[KB], xl0[KB], xh1[KB], xl1[KB];
 #pragma unroll
             for (int q = 0; q < KB; ++q) { xh0[q] = ph0[4 * q]; xl0[q] = pl0[4 * q]; xh1[q] = ph1[4 * q]; xl1[q] = pl1[4 * q]; }
-            // three independent accumulators per (feature tile, row tile): hi.hi (+ bias), hi.lo, lo.hi
-            v4f hh0[NCT], ca0[NCT], cb0[NCT], hh1[NCT], ca1[NCT], cb1[NCT];
+            // one accumulator per (feature tile, row tile), bias riding in it: hi.lo + lo.hi + hi.hi
+            v4f hh0[NCT], hh1[NCT];
 #pragma unroll
             for (int t = 0; t < NCT; ++t) {
                 hh0[t] = (v4f){ bv[t][0], bv[t][1], bv[t][2], bv[t][3] };
                 hh1[t] = hh0[t];
-                ca0[t] = cb0[t] = ca1[t] = cb1[t] = (v4f){ 0.f, 0.f, 0.f, 0.f };
             }
 #define CM_MFH(A, B, ACC) ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, ACC, 0, 0, 0)
-#if (CM_H_VARIANT & 1)
-            if (hasB) {
-#pragma unroll
-                for (int q = 0; q < KB; ++q) {
-#pragma unroll
-                    for (int t = 0; t < NCT; ++t) { CM_MFH(wh[t][q], xh0[q], hh0[t]); CM_MFH(wh[t][q], xh1[q], hh1[t]); }
-#pragma unroll
-                    for (int t = 0; t < NCT; ++t) { CM_MFH(wh[t][q], xl0[q], ca0[t]); CM_MFH(wh[t][q], xl1[q], ca1[t]); }
-#pragma unroll
-                    for (int t = 0; t < NCT; ++t) { CM_MFH(wl[t][q], xh0[q], ca0[t]); CM_MFH(wl[t][q], xh1[q], ca1[t]); }
-                }
-            } else {
-#pragma unroll
-                for (int q = 0; q < KB; ++q) {
-#pragma unroll
-                    for (int t = 0; t < NCT; ++t) { CM_MFH(wh[t][q], xh0[q], hh0[t]); CM_MFH(wh[t][q], xl0[q], ca0[t]); }
-#pragma unroll
-                    for (int t = 0; t < NCT; ++t) CM_MFH(wl[t][q], xh0[q], ca0[t]);
-                }
-            }
-#else
             if (hasB) {
 #pragma unroll
                 for (int q = 0; q < KB; ++q)
 #pragma unroll
                     for (int t = 0; t < NCT; ++t) {
+                        CM_MFH(wh[t][q], xl0[q], hh0[t]); CM_MFH(wh[t][q], xl1[q], hh1[t]);
+                        CM_MFH(wl[t][q], xh0[q], hh0[t]); CM_MFH(wl[t][q], xh1[q], hh1[t]);
                         CM_MFH(wh[t][q], xh0[q], hh0[t]); CM_MFH(wh[t][q], xh1[q], hh1[t]);
-                        CM_MFH(wh[t][q], xl0[q], ca0[t]); CM_MFH(wh[t][q], xl1[q], ca1[t]);
-                        CM_MFH(wl[t][q], xh0[q], cb0[t]); CM_MFH(wl[t][q], xh1[q], cb1[t]);
                     }
             } else {
 #pragma unroll
                 for (int q = 0; q < KB; ++q)
 #pragma unroll
                     for (int t = 0; t < NCT; ++t) {
-                        CM_MFH(wh[t][q], xh0[q], hh0[t]); CM_MFH(wh[t][q], xl0[q], ca0[t]); CM_MFH(wl[t][q], xh0[q], cb0[t]);
+                        CM_MFH(wh[t][q], xl0[q], hh0[t]); CM_MFH(wl[t][q], xh0[q], hh0[t]); CM_MFH(wh[t][q], xh0[q], hh0[t]);
                     }
             }
-#endif
 #undef CM_MFH
             // D layout: lane (c, g) holds features 16 ct + 4 g + r (r = 0..3) of row (row tile) * 16 + c
 #pragma unroll
@@ -187,9 +162,9 @@ struct LayerH {
                 float y0[4], y1[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float v0 = fmaf(ca0[t][r] + cb0[t][r], LO_INV, hh0[t][r]);
+                    const float v0 = hh0[t][r];
                     y0[r] = TANH ? fast_tanh(v0) : v0;
-                    const float v1 = fmaf(ca1[t][r] + cb1[t][r], LO_INV, hh1[t][r]);
+                    const float v1 = hh1[t][r];
                     y1[r] = TANH ? fast_tanh(v1) : v1;
                 }
                 if (OUTS & OUT_F32) {
@@ -236,18 +211,18 @@ struct LayerH {
             v8h xh0[KB], xl0[KB], xh1[KB], xl1[KB];
 #pragma unroll
             for (int q = 0; q < KB; ++q) { xh0[q] = ph0[4 * q]; xl0[q] = pl0[4 * q]; xh1[q] = ph1[4 * q]; xl1[q] = pl1[4 * q]; }
-            v4f hh0[NCT], cr0[NCT], hh1[NCT], cr1[NCT];
+            v4f hh0[NCT], hh1[NCT];
 #pragma unroll
-            for (int t = 0; t < NCT; ++t) hh0[t] = hh1[t] = cr0[t] = cr1[t] = (v4f){ 0.f, 0.f, 0.f, 0.f };
+            for (int t = 0; t < NCT; ++t) hh0[t] = hh1[t] = (v4f){ 0.f, 0.f, 0.f, 0.f };
 #define CM_MFH(A, B, ACC) ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, ACC, 0, 0, 0)
 #pragma unroll
             for (int q = 0; q < KB; ++q) {
 #pragma unroll
+                for (int t = 0; t < NCT; ++t) { CM_MFH(xl0[q], wh[t][q], hh0[t]); if (hasB) CM_MFH(xl1[q], wh[t][q], hh1[t]); }
+#pragma unroll
+                for (int t = 0; t < NCT; ++t) { CM_MFH(xh0[q], wl[t][q], hh0[t]); if (hasB) CM_MFH(xh1[q], wl[t][q], hh1[t]); }
+#pragma unroll
                 for (int t = 0; t < NCT; ++t) { CM_MFH(xh0[q], wh[t][q], hh0[t]); if (hasB) CM_MFH(xh1[q], wh[t][q], hh1[t]); }
-#pragma unroll
-                for (int t = 0; t < NCT; ++t) { CM_MFH(xl0[q], wh[t][q], cr0[t]); if (hasB) CM_MFH(xl1[q], wh[t][q], cr1[t]); }
-#pragma unroll
-                for (int t = 0; t < NCT; ++t) { CM_MFH(xh0[q], wl[t][q], cr0[t]); if (hasB) CM_MFH(xh1[q], wl[t][q], cr1[t]); }
             }
 #undef CM_MFH
 #pragma unroll
@@ -261,7 +236,7 @@ struct LayerH {
                         v4h oh, ol;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const float y = half == 0 ? fmaf(cr0[t][r], LO_INV, hh0[t][r]) : fmaf(cr1[t][r], LO_INV, hh1[t][r]);
+                            const float y = half == 0 ? hh0[t][r] : hh1[t][r];
                             h16 h, l; split2((r0 + r < rows) ? y : 0.0f, h, l); oh[r] = h; ol[r] = l;
                         }
                         const size_t o = ((size_t)e * EMB + f) * kstride + k;
@@ -283,16 +258,14 @@ __device__ __forceinline__ v4f scores_tile_h(const Planes Q, const Planes E, int
     const v8h *eh = reinterpret_cast<const v8h *>(E.hi + (size_t)rb * E.stride + 8 * g);
     const v8h *el = reinterpret_cast<const v8h *>(E.lo + (size_t)rb * E.stride + 8 * g);
     v8h a0 = qh[0], a1 = qh[4], al0 = ql[0], al1 = ql[4], b0 = eh[0], b1 = eh[4], bl0 = el[0], bl1 = el[4];
-    v4f hh = (v4f){ 0.f, 0.f, 0.f, 0.f }, ca = hh, cb = hh;
+    v4f hh = (v4f){ 0.f, 0.f, 0.f, 0.f };
+    hh = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bl0, hh, 0, 0, 0);
+    hh = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, b0, hh, 0, 0, 0);
+    hh = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bl1, hh, 0, 0, 0);
+    hh = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, b1, hh, 0, 0, 0);
     hh = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0, hh, 0, 0, 0);
-    ca = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bl0, ca, 0, 0, 0);
-    cb = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, b0, cb, 0, 0, 0);
     hh = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, hh, 0, 0, 0);
-    ca = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bl1, ca, 0, 0, 0);
-    cb = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, b1, cb, 0, 0, 0);
-    v4f sc;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) sc[r] = fmaf(ca[r] + cb[r], LO_INV, hh[r]);
+    v4f sc = hh;
     return sc;
 }
 
@@ -764,16 +737,15 @@ __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, c
                                 xh1[q] = *reinterpret_cast<const v8h *>(Am.hi + rb2 + 32 * qc); xl1[q] = *reinterpret_cast<const v8h *>(Am.lo + rb2 + 32 * qc);
                             }
                             v4f hh0 = (v4f){ bvr[0], bvr[1], bvr[2], bvr[3] }, hh1 = hh0;
-                            v4f ca0 = (v4f){ 0.f, 0.f, 0.f, 0.f }, ca1 = ca0, cb0 = ca0, cb1 = ca0;
 #pragma unroll
                             for (int q = 0; q < MAXKB; ++q) {
                                 if (q < KBQ) {
+                                    hh0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[q], xl0[q], hh0, 0, 0, 0);
+                                    hh1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[q], xl1[q], hh1, 0, 0, 0);
+                                    hh0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[q], xh0[q], hh0, 0, 0, 0);
+                                    hh1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[q], xh1[q], hh1, 0, 0, 0);
                                     hh0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[q], xh0[q], hh0, 0, 0, 0);
                                     hh1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[q], xh1[q], hh1, 0, 0, 0);
-                                    ca0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[q], xl0[q], ca0, 0, 0, 0);
-                                    ca1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[q], xl1[q], ca1, 0, 0, 0);
-                                    cb0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[q], xh0[q], cb0, 0, 0, 0);
-                                    cb1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[q], xh1[q], cb1, 0, 0, 0);
                                 }
                             }
                             // lane (c, g): features f0 .. f0+3 of rows rt*16 + c and (rt+1)*16 + c
@@ -789,7 +761,7 @@ __device__ __forceinline__ void fwd_body_h(const FwdArgs &a, const TrunkH &tw, c
                                     }
 #pragma unroll
                                     for (int r = 0; r < 4; ++r) {
-                                        const float pre = half == 0 ? fmaf(ca0[r] + cb0[r], LO_INV, hh0[r]) : fmaf(ca1[r] + cb1[r], LO_INV, hh1[r]);
+                                        const float pre = half == 0 ? hh0[r] : hh1[r];
                                         float hv = fast_tanh(pre);
                                         if (last && !a.no_residual) hv += join2(eh[r], el[r]);
                                         h16 h, lo_; split2(hv, h, lo_); oh[r] = h; ol[r] = lo_;
