@@ -65,6 +65,80 @@ def _dist_ready():
     return is_distributed()
 
 
+class _UpdateGraphs:
+    """hipGraphs of the optimiser steps of one train_once: the reference walks the SAME minibatches in each of its mini-epochs
+    (centralized_ma_ppo.py:209-268: one permutation per epoch), so a minibatch's step is the same ~130 launches on the same
+    buffers every time - only the weights, the Adam moments and the step number differ, and those live in device memory
+    (optim.Adam.begin_device_steps).  The first mini-epoch of a process goes eagerly (first-use set-up inside the library,
+    Adam's moments); after that a minibatch's step is captured the first time it comes up and every later step is one graph
+    launch.  For small batches the step is launch-bound (~3 ms of host work per step at the reference's 30 000 agent-steps per
+    epoch); large batches keep the eager path (COMMARL_UPDATE_GRAPH=1 forces the graphs, =0 disables them; the default
+    threshold is in agent rows per minibatch)."""
+    MAX_ROWS = 1 << 18
+
+    @classmethod
+    def maybe(cls, algo, minibatches, T, distributed):
+        mode = os.environ.get("COMMARL_UPDATE_GRAPH", "auto")
+        E = algo._optimization_mini_epochs
+        obs = minibatches[0][0]
+        if (mode == "0" or distributed or not obs.is_cuda or E < 3
+                or not all(hasattr(o, "begin_device_steps") for o in (algo._optimizer, algo._baseline_optimizer))):
+            return None
+        rows = max(mb[0].shape[0] for mb in minibatches) * T * algo.policy._n_agents
+        if mode != "1" and rows > cls.MAX_ROWS:
+            return None
+        # the first optimiser steps of a process go eagerly (first-use set-up inside the library, Adam's moment buffers and norm
+        # workspace); from then on the captures open in mini-epoch 0
+        first = 0 if getattr(algo, "_eager_stepped", False) else 1
+        return cls(algo, len(minibatches), (E - first) * len(minibatches), first)
+
+    def __init__(self, algo, n_mb, n_steps, first_epoch):
+        self.algo, self.graphs, self.done, self.n_steps, self.first_epoch = algo, [None] * n_mb, 0, n_steps, first_epoch
+        self.pool, self.stream = None, None
+        self.armed = False
+
+    def step(self, i, fn):
+        """Step of minibatch i (captured on first use) -> a copy of its gradient-norm output."""
+        if not self.armed:                                   # after mini-epoch 0: the moments exist, the step counts are known
+            self.algo._optimizer.begin_device_steps(self.n_steps)
+            self.algo._baseline_optimizer.begin_device_steps(self.n_steps)
+            self.armed = True
+        if self.graphs[i] is None:
+            # capture_begin / capture_end directly: torch.cuda.graph() would synchronise the device and empty the allocator's cache
+            # in front of every capture
+            g = torch.cuda.CUDAGraph()
+            cur = torch.cuda.current_stream()
+            if self.stream is None:
+                self.stream = torch.cuda.Stream(device=cur.device)
+            self.stream.wait_stream(cur)
+            # a capture freezes the host's decisions: the weight-pack cache must not answer "fresh" (it would, right after the
+            # epoch's no-grad forward) - the replays run after optimiser steps the host-side version counters never saw
+            for net in (self.algo.policy, self.algo.baseline):
+                if hasattr(net, "_pack_sig"):
+                    net._pack_sig = None
+            with L.capture_guard(), torch.cuda.stream(self.stream):
+                kw = {} if self.pool is None else dict(pool=self.pool)
+                g.capture_begin(capture_error_mode=os.environ.get("COMMARL_CAPTURE_MODE", "thread_local"), **kw)
+                try:
+                    out = fn()
+                finally:
+                    g.capture_end()
+            cur.wait_stream(self.stream)
+            if self.pool is None:
+                self.pool = g.pool()
+            self.graphs[i] = (g, out)
+        g, out = self.graphs[i]
+        g.replay()
+        self.done += 1
+        return out
+
+    def close(self):
+        if self.armed:
+            self.algo._optimizer.end_device_steps(self.done)
+            self.algo._baseline_optimizer.end_device_steps(self.done)
+        self.graphs = None
+
+
 class CentralizedMAPPO:
     def __init__(self, env_spec, policy, baseline, optimizer=None, baseline_optimizer=None,
                  optimization_n_minibatches=1, optimization_mini_epochs=1, policy_lr=3e-4, lr_clip_range=2e-1,
@@ -108,6 +182,7 @@ class CentralizedMAPPO:
         st = dict(self.__dict__)
         st.pop("_side_stream", None)
         st.pop("_bucket", None)
+        st.pop("_eager_stepped", None)                   # per process: the first optimiser steps of a process run eagerly
         return st
 
     @staticmethod
@@ -344,6 +419,17 @@ class CentralizedMAPPO:
             b = self._bucket = GradBucket(pol, cri)
         b.allreduce(n_valid, n_crit)
 
+    def _mean_grad_norm(self, grad_norm, dev):
+        """Mean over the epoch's optimiser steps of the norm the reference records AFTER the clip (:256):
+        |g| * min(1, max / (|g| + 1e-6)); optim.Adam hands over |g|^2 per step on the device, the rest is done once here."""
+        if not grad_norm:
+            return 0.0
+        if not torch.is_tensor(grad_norm[0]):
+            return float(np.mean(grad_norm))
+        pre = torch.stack(grad_norm).to(torch.float32).sqrt()
+        mx = float("inf") if self._clip_grad_norm is None else float(self._clip_grad_norm)
+        return float((pre * torch.clamp(mx / (pre + 1e-6), max=1.0)).mean())
+
     # ------------------------------------------------------------------------------------------
     # train_once (:175-388)
     # ------------------------------------------------------------------------------------------
@@ -398,44 +484,61 @@ class CentralizedMAPPO:
                                 sl(channels, ids), advantages[ids], old_ll[ids], returns[ids]))
         # The critic has its own trunk (a-17): its forward / backward (/ optimiser step) share nothing with the policy's
         # but the minibatch, so they run on a second HIP stream and fill the gaps of the policy's launch chain.
-        main = torch.cuda.current_stream(obs.device)
-        side = main
-        if obs.is_cuda and os.environ.get("COMMARL_CRITIC_STREAM", "1") != "0":
-            if getattr(self, "_side_stream", None) is None or self._side_stream.device != obs.device:
-                self._side_stream = torch.cuda.Stream(device=obs.device)
-            side = self._side_stream
-        for mini_epoch in range(self._optimization_mini_epochs):
-            for o, a, r, v, bl, da, ch, adv_mb, oll_mb, ret_mb in minibatches:
-                # critic: Gaussian NLL, mean over padded steps (comm_base_critic.py:88-89)
-                n_crit = torch.tensor(float(o.shape[0] * T), device=obs.device)
-                self._baseline_optimizer.zero_grad()
-                self._optimizer.zero_grad()
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    bl_loss = self._baseline_loss(o, ret_mb, da, ch)
-                    (bl_loss * n_crit if distributed else bl_loss).backward()
-                    if not distributed:
-                        self._baseline_optimizer.step()
-                loss_sum, n_valid = self._compute_loss(itr, o, None, a, r, v, bl, da, ch, adv_mb, oll_mb, reduce=False)
-                if distributed:
-                    loss_sum.backward()
-                    main.wait_stream(side)
-                    self._allreduce_grads(n_valid, n_crit)
-                else:
-                    (loss_sum / n_valid).backward()
-                if hasattr(self._optimizer, "_norm"):                               # optim.Adam: clip + update in two launches
-                    mx = float("inf") if self._clip_grad_norm is None else float(self._clip_grad_norm)
-                    pre = self._optimizer.step(max_norm=mx)                          # policy only (:253-255)
-                    # the reference records the norm AFTER the clip (:256): |g| * min(1, max / (|g| + 1e-6)), kept on the device
-                    grad_norm.append(pre * torch.clamp(mx / (pre + 1e-6), max=1.0))
-                else:
-                    if self._clip_grad_norm is not None:
-                        torch.nn.utils.clip_grad_norm_(self.policy.parameters(), self._clip_grad_norm)
-                    grad_norm.append(self.policy.grad_norm())
-                    self._optimizer.step()                                           # _optimize (:606-610)
-                if distributed:
+        two_streams = obs.is_cuda and os.environ.get("COMMARL_CRITIC_STREAM", "1") != "0"
+        if two_streams and (getattr(self, "_side_stream", None) is None or self._side_stream.device != obs.device):
+            self._side_stream = torch.cuda.Stream(device=obs.device)
+        n_crits = [torch.tensor(float(mb[0].shape[0] * T), device=obs.device) for mb in minibatches]
+
+        def one_step(mb, n_crit):
+            """One optimiser step of both nets on one minibatch (:211-268) -> the squared pre-clip gradient norm (device scalar,
+            optim.Adam) or the post-clip norm (host float, any other optimiser)."""
+            o, a, r, v, bl, da, ch, adv_mb, oll_mb, ret_mb = mb
+            main = torch.cuda.current_stream(obs.device)
+            side = self._side_stream if two_streams else main
+            # critic: Gaussian NLL, mean over padded steps (comm_base_critic.py:88-89)
+            self._baseline_optimizer.zero_grad()
+            self._optimizer.zero_grad()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                bl_loss = self._baseline_loss(o, ret_mb, da, ch)
+                (bl_loss * n_crit if distributed else bl_loss).backward()
+                if not distributed:
                     self._baseline_optimizer.step()
+            loss_sum, n_valid = self._compute_loss(itr, o, None, a, r, v, bl, da, ch, adv_mb, oll_mb, reduce=False)
+            if distributed:
+                loss_sum.backward()
                 main.wait_stream(side)
+                self._allreduce_grads(n_valid, n_crit)
+            else:
+                (loss_sum / n_valid).backward()
+            if hasattr(self._optimizer, "_norm"):                               # optim.Adam: clip + update in two launches
+                mx = float("inf") if self._clip_grad_norm is None else float(self._clip_grad_norm)
+                self._optimizer.step(max_norm=mx, return_norm=False)             # policy only (:253-255)
+                gn = self._optimizer.norm_sq                                     # a view of the optimiser's workspace
+            else:
+                if self._clip_grad_norm is not None:
+                    torch.nn.utils.clip_grad_norm_(self.policy.parameters(), self._clip_grad_norm)
+                gn = self.policy.grad_norm()
+                self._optimizer.step()                                           # _optimize (:606-610)
+            if distributed:
+                self._baseline_optimizer.step()
+            main.wait_stream(side)
+            return gn
+
+        # The permutation is drawn once per epoch, so mini-epochs 1.. repeat mini-epoch 0's launches on the same buffers with
+        # other weights: for the small (launch-bound) batches of the reference's own configuration each minibatch's step is
+        # captured into a hipGraph in mini-epoch 1 and replayed from then on (_UpdateGraphs).
+        graphs = _UpdateGraphs.maybe(self, minibatches, T, distributed)
+        for mini_epoch in range(self._optimization_mini_epochs):
+            for i, mb in enumerate(minibatches):
+                if graphs is not None and mini_epoch >= graphs.first_epoch:
+                    gn = graphs.step(i, lambda mb=mb, i=i: one_step(mb, n_crits[i]))
+                else:
+                    gn = one_step(mb, n_crits[i])
+                    self._eager_stepped = True
+                grad_norm.append(gn.clone() if torch.is_tensor(gn) else gn)
+        if graphs is not None:
+            graphs.close()
         torch.cuda.synchronize(obs.device)
         epoch_time = time.time() - t_opt
         self.policy.sync_weights()
@@ -455,8 +558,7 @@ class CentralizedMAPPO:
         avg_return = perf["AverageReturn"]
         self.stats = dict(perf, LossBefore=loss_before, LossAfter=loss_after,
                           dLoss=loss_before - loss_after, KLBefore=kl_before, KL=kl, Entropy=entropy,
-                          GradNorm=(float(torch.stack([torch.as_tensor(g, dtype=torch.float32, device=obs.device) for g in grad_norm]).mean())
-                                    if grad_norm else 0.0), EpochTime=epoch_time,
+                          GradNorm=self._mean_grad_norm(grad_norm, obs.device), EpochTime=epoch_time,
                           TrainOnceTime=time.time() - t_start, MaxPathLength=T,
                           EnvSteps=int(valids.sum().item()),
                           GPUMemoryMax=torch.cuda.max_memory_allocated(self._dev()) / 1024 ** 3)     # :372-383 (GiB)

@@ -22,6 +22,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <cmath>
 
 #include "cm_internal.h"
 
@@ -470,7 +471,13 @@ static int launch(long R, int KR, const float *x, const float *w, const float *d
     }
     const int n_cu = cm::cu_count();
     const long chunks = (R + ROWS - 1) / ROWS;
-    const int blocks = (int)std::min<long>(chunks, n_cu);
+    // One workgroup per CU for the large batches.  A small batch is spread over FEWER workgroups: every workgroup ends with one
+    // float atomic per weight-gradient element (4 - 8 k of them on the same addresses), ~0.1 us of serialised L2 atomics per
+    // workgroup against ~3 us per 64-row chunk streamed - the sum is least at ~sqrt(29 chunks) workgroups (measured on MI355X,
+    // tools/lin_bwd_sweep.py: 10 000 rows of 64 -> 64: 17 us with 64 workgroups, 32 us with one per chunk)
+    int blocks = (int)std::min<long>(std::min<long>(chunks, n_cu), std::max<long>(1, std::lround(std::sqrt(29.0 * (double)chunks))));
+    static const int force = [] { const char *e = getenv("COMMARL_LIN2_BLOCKS"); return e ? atoi(e) : 0; }();
+    if (force > 0) blocks = (int)std::min<long>(chunks, force);
     hipLaunchKernelGGL((bwd_kernel<KT, OT, ACT, LAYOUT, RAG, WO>), dim3(blocks), dim3(TPB), std::max<size_t>(lds, 33 * 1024), st, R, KR, x, w, dy, dy2, y, dx, dw,
                        db, obs, KO, dw1, db1);
     CM_HIP(hipGetLastError());

@@ -101,9 +101,21 @@ static int dispatch_h(const FwdArgs &a, const TrunkH &tw, const PolHeadH &ph, co
 // dst uint4 index ((ct * KB + q) * 2 + plane) * 64 + lane = halves e = 0..7 of W[o = 16 ct + (lane & 15)][k = 32 q + 8 (lane >> 4) + e]
 // *bad is raised when a weight cannot be carried by the (hi, lo) f16 pair: |w| > 65504 (the largest f16), inf or NaN would
 // turn into +-inf planes silently - cm_policy_pack / cm_critic_pack refuse such a net (pack_range_check below)
-__global__ void pack_layer_h_kernel(const float *__restrict__ Wt, int K, int OUT, int KB, int CT, uint4 *__restrict__ dst,
-                                    int *__restrict__ bad) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;                       // one (ct, q, lane): both planes
+// Every layer of a net in ONE launch: a table of (source, shape, destination) entries, block b works on the entry whose block range
+// holds it (a PPO optimiser step re-packs both nets, ~16 layers: one launch each instead of one per layer).
+constexpr int PACK_MAX_LAYERS = 12;
+struct PackJobsH {
+    const float *W[PACK_MAX_LAYERS]; uint4 *dst[PACK_MAX_LAYERS];
+    int K[PACK_MAX_LAYERS], OUT[PACK_MAX_LAYERS], KB[PACK_MAX_LAYERS], CT[PACK_MAX_LAYERS], first_block[PACK_MAX_LAYERS + 1];
+    int count;
+};
+__global__ void pack_layer_h_kernel(PackJobsH t, int *__restrict__ bad) {
+    int j = 0;
+    while (j + 1 < t.count && (int)blockIdx.x >= t.first_block[j + 1]) ++j;
+    const float *__restrict__ Wt = t.W[j];
+    uint4 *__restrict__ dst = t.dst[j];
+    const int K = t.K[j], OUT = t.OUT[j], KB = t.KB[j], CT = t.CT[j];
+    const int idx = ((int)blockIdx.x - t.first_block[j]) * 256 + threadIdx.x;   // one (ct, q, lane): both planes
     if (idx >= CT * KB * 64) return;
     const int lane = idx & 63, blk = idx >> 6, q = blk % KB, ct = blk / KB;
     const int o = 16 * ct + (lane & 15), k0 = 32 * q + 8 * (lane >> 4);
@@ -158,22 +170,34 @@ static int range_check_end(int *bad, void *stream, const char *what) {
     return CM_OK;
 }
 
-static int pack_one_h(const float *Wt, int K, int OUT, int kp, int out_pad, uint4 *dst, void *stream, int *bad) {
-    if (!Wt) return set_error(CM_ERR_ARG, "weight pack: null layer weight");
-    const int KB = kp / 32, CT = out_pad / 16, total = CT * KB * 64;
-    hipLaunchKernelGGL(pack_layer_h_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, Wt, K, OUT, KB, CT, dst, bad);
+static int pack_flush_h(PackJobsH &t, void *stream, int *bad) {
+    if (t.count == 0) return CM_OK;
+    hipLaunchKernelGGL(pack_layer_h_kernel, dim3(t.first_block[t.count]), dim3(256), 0, (hipStream_t)stream, t, bad);
     CM_HIP(hipGetLastError());
+    t.count = 0;
+    return CM_OK;
+}
+// queues one layer (launched by pack_flush_h; a full table is flushed on the way)
+static int pack_one_h(PackJobsH &t, const float *Wt, int K, int OUT, int kp, int out_pad, uint4 *dst, void *stream, int *bad) {
+    if (!Wt) return set_error(CM_ERR_ARG, "weight pack: null layer weight");
+    if (t.count == PACK_MAX_LAYERS)
+        if (int rc = pack_flush_h(t, stream, bad)) return rc;
+    const int KB = kp / 32, CT = out_pad / 16, total = CT * KB * 64, j = t.count;
+    if (j == 0) t.first_block[0] = 0;
+    t.W[j] = Wt; t.dst[j] = dst; t.K[j] = K; t.OUT[j] = OUT; t.KB[j] = KB; t.CT[j] = CT;
+    t.first_block[j + 1] = t.first_block[j] + (total + 255) / 256;
+    t.count = j + 1;
     return CM_OK;
 }
 
-static int pack_trunk_h(int d, int L, const float *w1t, const float *w2t, const float *wat, const float *gw, int kh,
+static int pack_trunk_h(PackJobsH &t, int d, int L, const float *w1t, const float *w2t, const float *wat, const float *gw, int kh,
                         const PackLayoutH &lo, uint4 *pack, void *stream, int *bad) {
-    if (int rc = pack_one_h(w1t, d, EH, kh, EH, pack + lo.enc1, stream, bad)) return rc;
-    if (int rc = pack_one_h(w2t, EH, EMB, EH, EMB, pack + lo.enc2, stream, bad)) return rc;
-    if (int rc = pack_one_h(wat, EMB, EMB, EMB, EMB, pack + lo.attn, stream, bad)) return rc;
+    if (int rc = pack_one_h(t, w1t, d, EH, kh, EH, pack + lo.enc1, stream, bad)) return rc;
+    if (int rc = pack_one_h(t, w2t, EH, EMB, EH, EMB, pack + lo.enc2, stream, bad)) return rc;
+    if (int rc = pack_one_h(t, wat, EMB, EMB, EMB, EMB, pack + lo.attn, stream, bad)) return rc;
     const size_t per = LayerH<EMB, EMB>::PACK_U4;
     for (int l = 0; l < L; ++l)
-        if (int rc = pack_one_h(gw ? gw + (size_t)l * EMB * EMB : nullptr, EMB, EMB, EMB, EMB, pack + lo.gcn + (size_t)l * per, stream, bad)) return rc;
+        if (int rc = pack_one_h(t, gw ? gw + (size_t)l * EMB * EMB : nullptr, EMB, EMB, EMB, EMB, pack + lo.gcn + (size_t)l * per, stream, bad)) return rc;
     return CM_OK;
 }
 
@@ -199,11 +223,13 @@ int policy_pack_h(const cm_policy_weights *w, void *dst, int sections, void *str
     uint4 *pack = reinterpret_cast<uint4 *>(dst);
     int *bad = (sections & CM_PACK_CHECK) ? mh::range_check_begin(stream) : nullptr;
     if (sections & CM_PACK_F16) {
-        if (int rc = mh::pack_trunk_h(w->d, w->n_hops, w->enc_w1t, w->enc_w2t, w->attn_wt, w->gcn_w, kh, lo, pack, stream, bad)) return rc;
-        if (int rc = mh::pack_one_h(w->hd_w1t, mf::EMB, mf::H1, mf::EMB, mf::H1, pack + lo.x1, stream, bad)) return rc;
-        if (int rc = mh::pack_one_h(w->hd_w2t, mf::H1, mf::H2, mf::H1, mf::H2, pack + lo.h2, stream, bad)) return rc;
-        if (int rc = mh::pack_one_h(w->hd_w3t, mf::H2, mf::H3, mf::H2, mf::H3, pack + lo.h3, stream, bad)) return rc;
-        if (int rc = mh::pack_one_h(w->hd_w4t, mf::H3, w->n_act, mf::H3, 16, pack + lo.h4, stream, bad)) return rc;
+        mh::PackJobsH t{};
+        if (int rc = mh::pack_trunk_h(t, w->d, w->n_hops, w->enc_w1t, w->enc_w2t, w->attn_wt, w->gcn_w, kh, lo, pack, stream, bad)) return rc;
+        if (int rc = mh::pack_one_h(t, w->hd_w1t, mf::EMB, mf::H1, mf::EMB, mf::H1, pack + lo.x1, stream, bad)) return rc;
+        if (int rc = mh::pack_one_h(t, w->hd_w2t, mf::H1, mf::H2, mf::H1, mf::H2, pack + lo.h2, stream, bad)) return rc;
+        if (int rc = mh::pack_one_h(t, w->hd_w3t, mf::H2, mf::H3, mf::H2, mf::H3, pack + lo.h3, stream, bad)) return rc;
+        if (int rc = mh::pack_one_h(t, w->hd_w4t, mf::H3, w->n_act, mf::H3, 16, pack + lo.h4, stream, bad)) return rc;
+        if (int rc = mh::pack_flush_h(t, stream, bad)) return rc;
     }
     // teams of 4: the wave-owned kernel's fragments (another k order, cm_policy_w.hip), behind this section
     if (sections & CM_PACK_WAVE)
@@ -217,8 +243,10 @@ int critic_pack_h(const cm_critic_weights *w, void *dst, int sections, void *str
     const mh::PackLayoutH lo = mh::pack_layout_h(kh, w->n_hops, false);
     uint4 *pack = reinterpret_cast<uint4 *>(dst);
     int *bad = (sections & CM_PACK_CHECK) ? mh::range_check_begin(stream) : nullptr;
-    if (int rc = mh::pack_trunk_h(w->d, w->n_hops, w->enc_w1t, w->enc_w2t, w->attn_wt, w->gcn_w, kh, lo, pack, stream, bad)) return rc;
-    if (int rc = mh::pack_one_h(w->dec_w1t, mf::EMB, mf::DH, mf::EMB, mf::DH, pack + lo.x1, stream, bad)) return rc;
+    mh::PackJobsH t{};
+    if (int rc = mh::pack_trunk_h(t, w->d, w->n_hops, w->enc_w1t, w->enc_w2t, w->attn_wt, w->gcn_w, kh, lo, pack, stream, bad)) return rc;
+    if (int rc = mh::pack_one_h(t, w->dec_w1t, mf::EMB, mf::DH, mf::EMB, mf::DH, pack + lo.x1, stream, bad)) return rc;
+    if (int rc = mh::pack_flush_h(t, stream, bad)) return rc;
     return mh::range_check_end(bad, stream, "cm_critic_pack");
 }
 

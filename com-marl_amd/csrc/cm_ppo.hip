@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void agg_bwd4_kernel(int S, const float *__res
                                                        const float *__restrict__ chan, long ch_stride, const float *__restrict__ hw,
                                                        const float *__restrict__ outv, const float *__restrict__ out_minus,
                                                        const float *__restrict__ d_out, float *__restrict__ d_attn,
-                                                       float *__restrict__ d_hw, float *__restrict__ d_bias) {
+                                                       float *__restrict__ d_hw, float *__restrict__ d_bias, int bias_reps) {
     __shared__ __attribute__((aligned(16))) float As[16][16];
     __shared__ float4 dbs[256];
     const int tid = threadIdx.x, grp = tid >> 4, c = tid & 15;
@@ -438,13 +438,16 @@ __global__ __launch_bounds__(256) void agg_bwd4_kernel(int S, const float *__res
         if (live) d_attn[(size_t)s * 16 + c] = mk * (da - tt) * (1.0f / den);
     }
     if (d_bias) {
+        // 64 atomics per workgroup on the same two cache lines: with 2048 workgroups they serialise in the L2 (0.8 ns each: 105 of the
+        // kernel's 312 us at 275 k envs) - the caller may hand `bias_reps` copies of the row, workgroup b adds into copy b % reps
+        float *dbp = d_bias + (size_t)(blockIdx.x % (unsigned)bias_reps) * 64;
         dbs[tid] = db;
         __syncthreads();
         if (tid < 16) {
             float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int g2 = 0; g2 < 16; ++g2) { const float4 u = dbs[g2 * 16 + tid]; sum.x += u.x; sum.y += u.y; sum.z += u.z; sum.w += u.w; }
-            atomicAdd(d_bias + 4 * tid + 0, sum.x); atomicAdd(d_bias + 4 * tid + 1, sum.y);
-            atomicAdd(d_bias + 4 * tid + 2, sum.z); atomicAdd(d_bias + 4 * tid + 3, sum.w);
+            atomicAdd(dbp + 4 * tid + 0, sum.x); atomicAdd(dbp + 4 * tid + 1, sum.y);
+            atomicAdd(dbp + 4 * tid + 2, sum.z); atomicAdd(dbp + 4 * tid + 3, sum.w);
         }
     }
 }
@@ -600,8 +603,16 @@ __global__ __launch_bounds__(256) void multi_norm_kernel(TensorTable t, float *w
     if (threadIdx.x == 0) ws[1 + blockIdx.x] = red[0];
 }
 
+// bc_tab / cursor (cm_multi_adam_step_dev): the two bias-correction factors come from a device table indexed by a device step
+// counter, so that a captured hipGraph of the optimiser step can be replayed for successive steps
 __global__ __launch_bounds__(256) void multi_adam_kernel(TensorTable t, float *norm_ws, float max_norm, float lr,
-                                                        float b1, float b2, float eps, float bc1, float sqrt_bc2) {
+                                                        float b1, float b2, float eps, float bc1, float sqrt_bc2,
+                                                        const float *__restrict__ bc_tab, const int32_t *__restrict__ cursor, int tab_steps) {
+    if (bc_tab) {
+        int c = *cursor;
+        c = c < 0 ? 0 : (c >= tab_steps ? tab_steps - 1 : c);
+        bc1 = bc_tab[2 * c]; sqrt_bc2 = bc_tab[2 * c + 1];
+    }
     float coef = 1.0f;
     if (norm_ws) {
         float nsq = 0.0f;
@@ -799,21 +810,115 @@ extern "C" int cm_multi_copy_t(int32_t n, const float *const *src, float *const 
     return CM_OK;
 }
 
-extern "C" int cm_multi_adam_step(int32_t n, float *const *params, float *const *grads, float *const *exp_avg, float *const *exp_avg_sq,
-                                  const int64_t *sizes, float *norm_ws, float max_norm, float lr, float beta1,
-                                  float beta2, float eps, int32_t step, void *stream) {
+static int multi_adam(int32_t n, float *const *params, float *const *grads, float *const *exp_avg, float *const *exp_avg_sq, const int64_t *sizes,
+                      float *norm_ws, float max_norm, float lr, float beta1, float beta2, float eps, int32_t step, const float *bc_tab,
+                      const int32_t *cursor, int32_t tab_steps, void *stream) {
     if (n < 0 || n > 40) return set_error(CM_ERR_ARG, "cm_multi_adam_step: at most 40 tensors per call");
     if (n == 0) return CM_OK;
-    if (!params || !grads || !exp_avg || !exp_avg_sq || !sizes || step < 1) return set_error(CM_ERR_ARG, "cm_multi_adam_step: bad argument");
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !sizes) return set_error(CM_ERR_ARG, "cm_multi_adam_step: bad argument");
+    if (bc_tab ? (!cursor || tab_steps < 1) : step < 1) return set_error(CM_ERR_ARG, "cm_multi_adam_step: bad step / bias-correction table");
     TensorTable t{};
     t.count = n;
     for (int k = 0; k < n; ++k) { t.p[k] = params[k]; t.g[k] = grads[k]; t.m[k] = exp_avg[k]; t.v[k] = exp_avg_sq[k]; t.n[k] = (long)sizes[k]; }
     const hipStream_t st = (hipStream_t)stream;
     if (norm_ws) hipLaunchKernelGGL(multi_norm_kernel, dim3(NORM_BLOCKS), dim3(256), 0, st, t, norm_ws);
+    const int hs = bc_tab ? 1 : step;
     hipLaunchKernelGGL(multi_adam_kernel, dim3(64), dim3(256), 0, st, t, norm_ws, max_norm, lr, beta1, beta2, eps,
-                       (float)(1.0 - pow((double)beta1, (double)step)), (float)sqrt(1.0 - pow((double)beta2, (double)step)));
+                       (float)(1.0 - pow((double)beta1, (double)hs)), (float)sqrt(1.0 - pow((double)beta2, (double)hs)), bc_tab, cursor,
+                       (int)tab_steps);
     CM_HIP(hipGetLastError());
     return CM_OK;
+}
+
+extern "C" int cm_multi_adam_step(int32_t n, float *const *params, float *const *grads, float *const *exp_avg, float *const *exp_avg_sq,
+                                  const int64_t *sizes, float *norm_ws, float max_norm, float lr, float beta1,
+                                  float beta2, float eps, int32_t step, void *stream) {
+    return multi_adam(n, params, grads, exp_avg, exp_avg_sq, sizes, norm_ws, max_norm, lr, beta1, beta2, eps, step, nullptr, nullptr, 0, stream);
+}
+
+extern "C" void cm_adam_bias_corrections(float beta1, float beta2, int32_t first_step, int32_t n_steps, float *table) {
+    for (int i = 0; i < n_steps; ++i) {
+        const double s = (double)first_step + i;
+        table[2 * i] = (float)(1.0 - pow((double)beta1, s));
+        table[2 * i + 1] = (float)sqrt(1.0 - pow((double)beta2, s));
+    }
+}
+
+extern "C" int cm_multi_adam_step_dev(int32_t n, float *const *params, float *const *grads, float *const *exp_avg, float *const *exp_avg_sq,
+                                      const int64_t *sizes, float *norm_ws, float max_norm, float lr, float beta1, float beta2, float eps,
+                                      const float *bc_table, const int32_t *cursor, int32_t table_steps, void *stream) {
+    return multi_adam(n, params, grads, exp_avg, exp_avg_sq, sizes, norm_ws, max_norm, lr, beta1, beta2, eps, 0, bc_table, cursor, table_steps,
+                      stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Gaussian negative log-likelihood of the critic (comm_base_critic.py:59-89: -Normal(values, std.mean()).log_prob(returns).mean()
+// with values = the per-agent outputs summed over the team (:110-112) and std = exp(clamp(log_std, min)) of
+// gaussian_mlp_module.py:62-188) in ONE launch, and its gradient in one more - the framework spells the same arithmetic as
+// ~25 elementwise / reduction launches forward and as many backward, which at the reference's batch size is half of an
+// optimiser step's launches.  Normal.log_prob's own expression is kept: var = sigma^2, log_scale = log(sigma),
+//   loss = mean_s[(r_s - v_s)^2] / (2 var) + log_scale + log(sqrt(2 pi))
+// The sum of squares is accumulated in f64 (block sums + one f64 atomic per block); the last block to finish writes the two
+// results and clears the workspace for the next launch.
+// ---------------------------------------------------------------------------------------------------------------
+struct GaussWs { double sum; unsigned int done; unsigned int pad; };
+
+__device__ __forceinline__ float gauss_sigma(const float *log_std, float min_log_std, int has_min) {
+    float ls = log_std[0];
+    if (has_min) ls = fmaxf(ls, min_log_std);
+    return expf(ls);
+}
+
+__global__ __launch_bounds__(256) void gauss_nll_fwd_kernel(long S, int N, const float *__restrict__ per_agent, const float *__restrict__ returns,
+                                                            const float *__restrict__ log_std, float min_log_std, int has_min,
+                                                            float *__restrict__ out, GaussWs *__restrict__ ws) {
+    double part = 0.0;
+    for (long s = (long)blockIdx.x * 256 + threadIdx.x; s < S; s += (long)gridDim.x * 256) {
+        float v = 0.0f;
+        for (int i = 0; i < N; ++i) v += per_agent[s * N + i];
+        const float d = returns[s] - v;
+        part += (double)(d * d);
+    }
+    __shared__ double red[256];
+    __shared__ bool last;
+    red[threadIdx.x] = part;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) { if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
+    if (threadIdx.x == 0) {
+        atomicAdd(&ws->sum, red[0]);
+        __threadfence();
+        last = atomicAdd(&ws->done, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        __threadfence();
+        const double total = atomicAdd(&ws->sum, 0.0);             // through L2, after every block's contribution
+        const float msq = (float)(total / (double)S);
+        const float sigma = gauss_sigma(log_std, min_log_std, has_min);
+        const float var = sigma * sigma, log_scale = logf(sigma);
+        out[0] = msq / (2.0f * var) + log_scale + 0.918938533204672742f;   // log(sqrt(2 pi))
+        out[1] = msq;
+        ws->sum = 0.0;
+        ws->done = 0u;
+    }
+}
+
+// d loss / d per_agent[s][i] = -(r_s - v_s) / (var S);  d loss / d log_std = 1 - msq / var (zero below the clamp);  both times *g
+__global__ __launch_bounds__(256) void gauss_nll_bwd_kernel(long S, int N, const float *__restrict__ per_agent, const float *__restrict__ returns,
+                                                            const float *__restrict__ log_std, float min_log_std, int has_min,
+                                                            const float *__restrict__ out, const float *__restrict__ g,
+                                                            float *__restrict__ d_per_agent, float *__restrict__ d_log_std) {
+    const float sigma = gauss_sigma(log_std, min_log_std, has_min), var = sigma * sigma;
+    const float gs = g ? g[0] : 1.0f;
+    const float k = -gs / (var * (float)S);
+    for (long s = (long)blockIdx.x * 256 + threadIdx.x; s < S; s += (long)gridDim.x * 256) {
+        float v = 0.0f;
+        for (int i = 0; i < N; ++i) v += per_agent[s * N + i];
+        const float dv = k * (returns[s] - v);
+        for (int i = 0; i < N; ++i) d_per_agent[s * N + i] = dv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && d_log_std)
+        d_log_std[0] = (has_min && log_std[0] < min_log_std) ? 0.0f : gs * (1.0f - out[1] / var);
 }
 
 static size_t agg_lds_fwd(int N, int E) { const int epb = agg_epb(N), rows = epb * N; return ((size_t)rows * (N | 1) + (size_t)rows * (E + 4)) * 4; }
@@ -842,13 +947,24 @@ extern "C" int cm_masked_agg_forward(int32_t S, int32_t N, int32_t E, const floa
 extern "C" int cm_masked_agg_backward(int32_t S, int32_t N, int32_t E, const float *attn, const float *dist_adj,
                                       const float *chan, int64_t ch_stride, const float *hw, const float *out, const float *out_minus,
                                       const float *d_out, float *d_attn, float *d_hw, float *d_bias, void *stream) {
+    return cm_masked_agg_backward_r(S, N, E, attn, dist_adj, chan, ch_stride, hw, out, out_minus, d_out, d_attn, d_hw, d_bias, 1, stream);
+}
+
+extern "C" int cm_masked_agg_backward_r(int32_t S, int32_t N, int32_t E, const float *attn, const float *dist_adj,
+                                        const float *chan, int64_t ch_stride, const float *hw, const float *out, const float *out_minus,
+                                        const float *d_out, float *d_attn, float *d_hw, float *d_bias, int32_t bias_replicas, void *stream) {
     if (!attn || !hw || !out || !d_out || !d_attn || !d_hw) return set_error(CM_ERR_ARG, "cm_masked_agg_backward: null argument");
+    if (bias_replicas < 1) return set_error(CM_ERR_ARG, "cm_masked_agg_backward: bias_replicas >= 1 required");
     if (E != 64) return set_error(CM_ERR_ARG, "cm_masked_agg_backward: embedding dim 64 only");
     if (S <= 0) return CM_OK;
     if (N == 4 && quad_bwd_on() && !(((uintptr_t)hw | (uintptr_t)out | (uintptr_t)out_minus | (uintptr_t)d_out | (uintptr_t)d_hw) & 15)) {
-        const int blocks = (int)std::min<long>((S + 15) / 16, 2048);
+        // small batches: fewer workgroups looping (the bias atomics again: 2 500 envs take 11.6 us on 64 workgroups, 19 on 157)
+        const long chunks = ((long)S + 15) / 16;
+        int blocks = (int)(chunks <= 512 ? std::min<long>(chunks, 64) : std::min<long>(chunks, 2048));
+        static const int force = [] { const char *e = getenv("COMMARL_AGG4_BLOCKS"); return e ? atoi(e) : 0; }();
+        if (force > 0) blocks = std::min(blocks, force);
         hipLaunchKernelGGL(agg_bwd4_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, S, attn, dist_adj, chan, (long)ch_stride, hw, out,
-                           out_minus, d_out, d_attn, d_hw, d_bias);
+                           out_minus, d_out, d_attn, d_hw, d_bias, (int)bias_replicas);
         CM_HIP(hipGetLastError());
         return CM_OK;
     }
@@ -964,6 +1080,28 @@ extern "C" int cm_ppo_surrogate(int32_t P, int32_t T, int32_t N, int32_t A, cons
     const long S = (long)P * T;
     hipLaunchKernelGGL(ppo_surrogate_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P, T, N, A, logits, actions,
                        old_ll, adv, lens, clip, ent_coeff, add_entropy, total, (long long *)count, dlogits);
+    CM_HIP(hipGetLastError());
+    return CM_OK;
+}
+
+extern "C" int cm_gauss_nll_forward(int64_t S, int32_t N, const float *per_agent, const float *returns, const float *log_std, float min_log_std,
+                                    int32_t has_min, float *out, void *ws, void *stream) {
+    if (!per_agent || !returns || !log_std || !out || !ws) return set_error(CM_ERR_ARG, "cm_gauss_nll_forward: null argument");
+    if (S < 1 || N < 1) return set_error(CM_ERR_ARG, "cm_gauss_nll_forward: S >= 1 and n_agents >= 1 required");
+    const int blocks = (int)std::min<long>((S + 255) / 256, 256);
+    hipLaunchKernelGGL(gauss_nll_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (long)S, N, per_agent, returns, log_std, min_log_std,
+                       has_min, out, reinterpret_cast<GaussWs *>(ws));
+    CM_HIP(hipGetLastError());
+    return CM_OK;
+}
+
+extern "C" int cm_gauss_nll_backward(int64_t S, int32_t N, const float *per_agent, const float *returns, const float *log_std, float min_log_std,
+                                     int32_t has_min, const float *out, const float *g, float *d_per_agent, float *d_log_std, void *stream) {
+    if (!per_agent || !returns || !log_std || !out || !d_per_agent) return set_error(CM_ERR_ARG, "cm_gauss_nll_backward: null argument");
+    if (S < 1 || N < 1) return set_error(CM_ERR_ARG, "cm_gauss_nll_backward: S >= 1 and n_agents >= 1 required");
+    const int blocks = (int)std::min<long>((S + 255) / 256, 1024);
+    hipLaunchKernelGGL(gauss_nll_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (long)S, N, per_agent, returns, log_std, min_log_std,
+                       has_min, out, g, d_per_agent, d_log_std);
     CM_HIP(hipGetLastError());
     return CM_OK;
 }

@@ -299,8 +299,8 @@ class _ZeroPool:
     """The weight / bias gradients of one backward pass as views of ONE zero-filled buffer (one fill launch instead of one per
     tensor; the kernels accumulate into them with float atomics, so they must start at zero).  Views are 16-byte aligned."""
 
-    def __init__(self, params, device):
-        total = sum((p.numel() + 3) & ~3 for p in params)
+    def __init__(self, params, device, extra=0):
+        total = sum((p.numel() + 3) & ~3 for p in params) + extra
         self.buf = torch.zeros(total, dtype=torch.float32, device=device)
         self.off = 0
 
@@ -406,7 +406,7 @@ class _FusedNetFn(torch.autograd.Function):
         S = R // N
         P = dict(net.named_parameters())
         g = {}
-        pool = _ZeroPool(list(P.values()), obs2.device)
+        pool = _ZeroPool(list(P.values()), obs2.device, extra=31 * 64 * len(net.gcn_layers))   # (+ the bias-gradient replicas below)
         if ctx.policy:
             hd = net.categorical_output_layer
             lins = [l.linear for l in hd._layers] + [hd._output_layers[0].linear]
@@ -432,13 +432,17 @@ class _FusedNetFn(torch.autograd.Function):
                 gl = net.gcn_layers[l]
                 minus = e if (l == Lh - 1 and net.residual) else None       # saved x = E + H_L: the hop's tanh output is x - E
                 da, dhw = torch.empty_like(attn), torch.empty_like(e)
-                dgb = pool.take((64,)) if gl.bias is not None else None
+                # large batches of teams of 4: the bias gradient over 32 rows summed afterwards (cm_masked_agg_backward_r)
+                reps = 32 if (N == 4 and S > 16 * 512) else 1
+                dgb = pool.take((reps, 64)) if gl.bias is not None else None
                 chan_ptr, stride = None, 0
                 if ch is not None:
                     chan_ptr, stride = ch.data_ptr() + 4 * l * N * N, ch.shape[1] * N * N
-                L.check(L.lib().cm_masked_agg_backward(S, N, 64, L.ptr(attn), L.ptr(adj), chan_ptr, stride, L.ptr(t["hw"][l]),
-                                                       L.ptr(t["h"][l]), L.ptr(minus), L.ptr(dH), L.ptr(da), L.ptr(dhw), L.ptr(dgb),
-                                                       L.current_stream()), "cm_masked_agg_backward")
+                L.check(L.lib().cm_masked_agg_backward_r(S, N, 64, L.ptr(attn), L.ptr(adj), chan_ptr, stride, L.ptr(t["hw"][l]),
+                                                         L.ptr(t["h"][l]), L.ptr(minus), L.ptr(dH), L.ptr(da), L.ptr(dhw), L.ptr(dgb),
+                                                         reps, L.current_stream()), "cm_masked_agg_backward_r")
+                if dgb is not None:
+                    dgb = dgb.sum(0) if reps > 1 else dgb[0]
                 d_attn = da if d_attn is None else d_attn.add_(da)
                 hin = t["h"][l - 1] if l > 0 else e
                 dhin, g["gcn_layers.%d.weight" % l], _ = _lin_bwd(hin, gl.weight, 1, dhw, None, True, False, pool=pool)
@@ -516,6 +520,13 @@ def _as_dev(x, device):
     return x.to(device=device, dtype=torch.float32)
 
 
+class _Stacked(list):
+    """Equal-shape parameters that the flat weight copy stores back to back (what torch.stack would give, without its launch)."""
+
+    def numel(self):
+        return sum(t.numel() for t in self)
+
+
 class _WeightPack:
     """Flat device copy of a net's (transposed) weights for the fused C-ABI kernels; subclasses list the
     tensors in ``_pack_tensors()``."""
@@ -558,24 +569,22 @@ class _WeightPack:
 
     def _flat_copy(self, ts, buf, offs):
         """Every tensor of `ts` into its slot of the flat buffer.  On the GPU: ONE launch (cm_multi_copy_t) for all the plain
-        parameters and transposed weight views (`weight.t()`: the source is the parameter itself, the kernel transposes); anything
-        else (stacked GCN weights, ...) through the framework's copy."""
+        parameters and transposed weight views (`weight.t()`: the source is the parameter itself, the kernel transposes; a
+        _Stacked group entry by entry); anything else through the framework's copy."""
         plain = []
         for k, v in ts.items():
             if v is None:
                 continue
             o, n = offs[k]
-            dst = buf[o:o + n]
-            base = v._base if (v.dim() == 2 and v._base is not None and not v.is_contiguous()) else None
-            if (buf.is_cuda and v.dtype == torch.float32 and v.dim() <= 2 and len(plain) < 40
-                    and (v.is_contiguous() or (base is not None and base.is_contiguous() and base.dim() == 2
-                                               and base.shape == v.shape[::-1] and v.data_ptr() == base.data_ptr()))):
-                if v.is_contiguous():
-                    plain.append((v.data_ptr(), dst.data_ptr(), 1, n, 0))
-                else:                                        # v = base.t(): dst[c][r] = base[r][c]
-                    plain.append((base.data_ptr(), dst.data_ptr(), base.shape[0], base.shape[1], 1))
+            if isinstance(v, _Stacked):                      # the stack's members one after the other
+                parts, po = [], o
+                for t in v:
+                    parts.append((t, po, t.numel()))
+                    po += t.numel()
             else:
-                dst.copy_(v.detach().to(torch.float32).reshape(-1))
+                parts = [(v, o, n)]
+            for v, o, n in parts:
+                self._flat_copy_one(v, buf[o:o + n], n, plain, buf)
         if plain:
             m = len(plain)
             src = (C.c_void_p * m)(*[t[0] for t in plain])
@@ -585,6 +594,19 @@ class _WeightPack:
             tr = (C.c_int32 * m)(*[t[4] for t in plain])
             with torch.cuda.device(buf.device):
                 L.check(L.lib().cm_multi_copy_t(m, src, dstp, rows, cols, tr, L.current_stream()), "cm_multi_copy_t")
+
+    @staticmethod
+    def _flat_copy_one(v, dst, n, plain, buf):
+        base = v._base if (v.dim() == 2 and v._base is not None and not v.is_contiguous()) else None
+        if (buf.is_cuda and v.dtype == torch.float32 and v.dim() <= 2 and len(plain) < 40
+                and (v.is_contiguous() or (base is not None and base.is_contiguous() and base.dim() == 2
+                                           and base.shape == v.shape[::-1] and v.data_ptr() == base.data_ptr()))):
+            if v.is_contiguous():
+                plain.append((v.data_ptr(), dst.data_ptr(), 1, n, 0))
+            else:                                            # v = base.t(): dst[c][r] = base[r][c]
+                plain.append((base.data_ptr(), dst.data_ptr(), base.shape[0], base.shape[1], 1))
+        else:
+            dst.copy_(v.detach().to(torch.float32).reshape(-1))
 
     def _after_pack(self, ptrs, sections=15):
         """Hook: derived device-side layouts (the matrix-core operand pack) are rebuilt here."""
@@ -670,8 +692,8 @@ class CommBaseNet(_WeightPack, nn.Module):
             t["attn_wt"] = self.attention_layer.linear_in.weight.t()
         else:                                   # 'dot': Q = E, i.e. the fused kernels' linear_in is the identity (a constant)
             t["attn_wt"] = torch.eye(self._embedding_dim, dtype=torch.float32, device=next(self.parameters()).device)
-        t["gcn_w"] = torch.stack([g.weight for g in self.gcn_layers]) if len(self.gcn_layers) else None
-        t["gcn_b"] = (torch.stack([g.bias for g in self.gcn_layers])
+        t["gcn_w"] = _Stacked(g.weight for g in self.gcn_layers) if len(self.gcn_layers) else None
+        t["gcn_b"] = (_Stacked(g.bias for g in self.gcn_layers)
                       if len(self.gcn_layers) and self.gcn_layers[0].bias is not None else None)
         return t
 
@@ -938,6 +960,36 @@ class GaussianMLPModule(nn.Module):
         return mean, ls.exp()
 
 
+class _GaussNLLFn(torch.autograd.Function):
+    """The critic's Gaussian NLL from the per-agent outputs in one launch, its gradient in one more (cm_gauss_nll_*:
+    comm_base_critic.py:59-89 + :110-112 + the std of gaussian_mlp_module.py) instead of ~25 framework launches each way."""
+
+    @staticmethod
+    def forward(ctx, per_agent, returns, log_std, min_log_std, ws):
+        S, N = per_agent.shape
+        pa, r = per_agent.contiguous(), returns.contiguous()
+        out = torch.empty(2, dtype=torch.float32, device=pa.device)
+        has_min = 0 if min_log_std is None else 1
+        with torch.cuda.device(pa.device):
+            L.check(L.lib().cm_gauss_nll_forward(S, N, L.ptr(pa), L.ptr(r), L.ptr(log_std), float(min_log_std or 0.0), has_min, L.ptr(out),
+                                                 L.ptr(ws), L.current_stream()), "cm_gauss_nll_forward")
+        ctx.save_for_backward(pa, r, log_std, out)
+        ctx.min_log_std = min_log_std
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        pa, r, log_std, out = ctx.saved_tensors
+        S, N = pa.shape
+        d_pa, d_ls = torch.empty_like(pa), torch.empty_like(log_std)
+        g = g.to(torch.float32).contiguous()
+        with torch.cuda.device(pa.device):
+            L.check(L.lib().cm_gauss_nll_backward(S, N, L.ptr(pa), L.ptr(r), L.ptr(log_std), float(ctx.min_log_std or 0.0),
+                                                  0 if ctx.min_log_std is None else 1, L.ptr(out), L.ptr(g), L.ptr(d_pa), L.ptr(d_ls),
+                                                  L.current_stream()), "cm_gauss_nll_backward")
+        return d_pa, None, d_ls, None, None
+
+
 class CommBaseCritic(CommBaseNet):
     """comm_base_critic.py:11-122, aggregators 'sum' and 'direct' (same ctor kwargs as runner_pp_commDP.py:63-74)."""
 
@@ -981,6 +1033,10 @@ class CommBaseCritic(CommBaseNet):
             setattr(w, k, v)
         return w
 
+    def _fused_head_ok(self, obs):
+        return (self.aggregator_type == "sum" and _fused_train_ok(self, obs)
+                and len(self.baseline_aggregator._mean_module._layers) == 1)
+
     def _values_grad(self, obs_n, dist_adj, channels):
         lead, S, obs, adj, ch = self._flatten(obs_n, dist_adj, channels)
         if self.aggregator_type == "direct":
@@ -988,7 +1044,7 @@ class CommBaseCritic(CommBaseNet):
             x = E + H if self.residual else H
             mean, std = self.baseline_aggregator(x.reshape(S, -1))                   # concatenated embeddings (:113-115)
             return mean.squeeze(-1).reshape(*lead), std
-        if _fused_train_ok(self, obs) and len(self.baseline_aggregator._mean_module._layers) == 1:
+        if self._fused_head_ok(obs):
             per_agent, _ = _FusedNetFn.apply(self, obs, adj, ch, *self.parameters())  # [S,N] per-agent means
             ag = self.baseline_aggregator
             ls = ag._init_std if ag._min_std_param is None else ag._init_std.clamp(min=ag._min_std_param)
@@ -1031,8 +1087,19 @@ class CommBaseCritic(CommBaseNet):
 
     def compute_loss(self, obs_n, returns, dist_adj, channels, get_actions=False):
         """Gaussian NLL with the shared learned std; padded steps are included in the mean (:59-89)."""
+        lead, S, obs, adj, ch = self._flatten(obs_n, dist_adj, channels)
+        ag = self.baseline_aggregator
+        if (self._fused_head_ok(obs) and torch.is_tensor(returns) and returns.is_cuda and returns.dtype == torch.float32
+                and ag._init_std.numel() == 1 and os.environ.get("COMMARL_FUSED_NLL", "1") != "0"):
+            per_agent, _ = _FusedNetFn.apply(self, obs, adj, ch, *self.parameters())  # [S,N] per-agent means
+            ws = getattr(self, "_nll_ws", None)
+            if ws is None or ws.device != per_agent.device:
+                ws = self._nll_ws = torch.zeros(2, dtype=torch.float64, device=per_agent.device)   # CM_GAUSS_WS_BYTES, left zero by each launch
+            return _GaussNLLFn.apply(per_agent, returns.reshape(-1), ag._init_std, ag._min_std_param, ws)
         values, std = self._values_grad(obs_n, dist_adj, channels)
-        return -Normal(values, std.mean()).log_prob(returns).mean()
+        # validate_args=False: the constructor's argument check reads a device flag back (a host sync per optimiser step, and not
+        # capturable into the update's hipGraphs); a non-finite value still surfaces - as a NaN loss in the epoch's statistics
+        return -Normal(values, std.mean(), validate_args=False).log_prob(returns).mean()
 
 
 # ---------------------------------------------------------------------------------------------
@@ -1289,4 +1356,4 @@ class GaussianMLPBaseline(_WeightPack, nn.Module):
     def compute_loss(self, obs, returns):
         _RowMLPPolicy._need_gpu(obs)
         mean, std = self.module(obs.reshape(-1, self.input_dim))                  # :93-96
-        return -Normal(mean, std).log_prob(returns.reshape(-1, 1)).mean()
+        return -Normal(mean, std, validate_args=False).log_prob(returns.reshape(-1, 1)).mean()      # (no host sync, as above)

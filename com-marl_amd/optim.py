@@ -19,10 +19,41 @@ class Adam(torch.optim.Optimizer):
             raise NotImplementedError("the runners use plain Adam (no weight decay, no amsgrad)")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False))
         self._norm = None
+        self.norm_sq = None
+        self._dev_steps = None
+
+    # ------------------------------------------------------------------------------------------
+    # device-side step counter: lets ONE captured hipGraph of an optimiser step be replayed for successive steps
+    # ------------------------------------------------------------------------------------------
+    def begin_device_steps(self, n_steps):
+        """From now until end_device_steps(), step() reads the bias corrections of step `step + 1 + cursor` from a device table
+        and advances the device cursor itself (both captured with the step); the host-side ``state[p]['step']`` stands still."""
+        ps = [p for g in self.param_groups for p in g["params"] if p.grad is not None or self.state[p]]
+        steps = {int(self.state[p]["step"]) for p in ps if self.state[p]}
+        assert len(steps) == 1 and len(self.param_groups) == 1, "device steps: one parameter group that has stepped together"
+        first = steps.pop() + 1
+        b1, b2 = self.param_groups[0]["betas"]
+        host = torch.empty(n_steps, 2, dtype=torch.float32)
+        L.lib().cm_adam_bias_corrections(float(b1), float(b2), first, n_steps, host.data_ptr())
+        dev = ps[0].device
+        self._dev_steps = dict(table=host.to(dev), cursor=torch.zeros(1, dtype=torch.int32, device=dev), n=n_steps, params=ps)
+
+    def end_device_steps(self, n_done):
+        """Book the `n_done` replayed steps into the host-side state (and the parameters' version counters)."""
+        ds, self._dev_steps = self._dev_steps, None
+        if ds is None:
+            return
+        assert 0 <= n_done <= ds["n"]
+        for p in ds["params"]:
+            self.state[p]["step"] = int(self.state[p]["step"]) + n_done
+            if n_done:
+                torch.autograd.graph.increment_version(p)
 
     @torch.no_grad()
-    def step(self, closure=None, max_norm=None):
-        """-> pre-clip gradient norm (device scalar tensor) when max_norm is given, else None."""
+    def step(self, closure=None, max_norm=None, return_norm=True):
+        """-> pre-clip gradient norm (device scalar tensor) when max_norm is given, else None.  return_norm=False skips the
+        square-root launch: the caller reads |g|^2 from ``norm_sq`` (a view of the kernels' workspace, overwritten by the next
+        step)."""
         assert closure is None
         out = None
         for group in self.param_groups:
@@ -39,10 +70,12 @@ class Adam(torch.optim.Optimizer):
                     st["step"] = 0
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] = int(st["step"]) + 1
+                if self._dev_steps is None:
+                    st["step"] = int(st["step"]) + 1
             steps = {int(self.state[p]["step"]) for p in ps}
             assert len(steps) == 1, "parameters of one group step together"
             step = steps.pop()
+            ds = self._dev_steps
             grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in ps]
             for p, g in zip(ps, grads):
                 if g is not p.grad:
@@ -59,15 +92,25 @@ class Adam(torch.optim.Optimizer):
             if n > 40:
                 raise L.CommarlError("cm_multi_adam_step takes at most 40 tensors per parameter group")
             with torch.cuda.device(dev):
-                L.check(L.lib().cm_multi_adam_step(
-                    n, arr(ps), arr(grads), arr([self.state[p]["exp_avg"] for p in ps]),
-                    arr([self.state[p]["exp_avg_sq"] for p in ps]), sizes, norm_ptr,
-                    float(max_norm if max_norm is not None else 0.0), float(group["lr"]), float(b1), float(b2),
-                    float(group["eps"]), step, L.current_stream()), "cm_multi_adam_step")
+                if ds is not None:
+                    L.check(L.lib().cm_multi_adam_step_dev(
+                        n, arr(ps), arr(grads), arr([self.state[p]["exp_avg"] for p in ps]),
+                        arr([self.state[p]["exp_avg_sq"] for p in ps]), sizes, norm_ptr,
+                        float(max_norm if max_norm is not None else 0.0), float(group["lr"]), float(b1), float(b2),
+                        float(group["eps"]), ds["table"].data_ptr(), ds["cursor"].data_ptr(), ds["n"], L.current_stream()),
+                        "cm_multi_adam_step_dev")
+                    ds["cursor"].add_(1)
+                else:
+                    L.check(L.lib().cm_multi_adam_step(
+                        n, arr(ps), arr(grads), arr([self.state[p]["exp_avg"] for p in ps]),
+                        arr([self.state[p]["exp_avg_sq"] for p in ps]), sizes, norm_ptr,
+                        float(max_norm if max_norm is not None else 0.0), float(group["lr"]), float(b1), float(b2),
+                        float(group["eps"]), step, L.current_stream()), "cm_multi_adam_step")
             # the kernel wrote through raw pointers: tell torch (and the nets' weight-pack cache, which keys on the version
             # counters) that the parameters changed
             for p in ps:
                 torch.autograd.graph.increment_version(p)
                 if max_norm is not None:
                     torch.autograd.graph.increment_version(p.grad)
-        return None if out is None else out.sqrt()
+        self.norm_sq = out
+        return None if (out is None or not return_norm) else out.sqrt()

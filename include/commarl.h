@@ -328,6 +328,12 @@ int cm_masked_agg_forward(int32_t S, int32_t N, int32_t E, const float *attn, co
 int cm_masked_agg_backward(int32_t S, int32_t N, int32_t E, const float *attn, const float *dist_adj,
                            const float *chan, int64_t ch_stride, const float *hw, const float *out, const float *out_minus,
                            const float *d_out, float *d_attn, float *d_hw, float *d_bias, void *stream);
+/* The same with the bias gradient spread over `bias_replicas` >= 1 rows: d_bias [bias_replicas][E], zero on entry like every
+ * accumulated gradient; a workgroup adds its column sums into ONE of the rows and the caller sums the rows.  (All workgroups adding
+ * into one 256-byte row serialise in the L2: a third of the teams-of-4 kernel's time at a million agent rows.) */
+int cm_masked_agg_backward_r(int32_t S, int32_t N, int32_t E, const float *attn, const float *dist_adj,
+                             const float *chan, int64_t ch_stride, const float *hw, const float *out, const float *out_minus,
+                             const float *d_out, float *d_attn, float *d_hw, float *d_bias, int32_t bias_replicas, void *stream);
 
 /* Attention scores + softmax for the autograd path (attention_module.py:39-49):
  *   m[s,i,:] = softmax_j(q[s,i,:] . e[s,j,:]),  q = linear_in(e) [S,N,E], e [S,N,E], m [S,N,N].
@@ -383,6 +389,28 @@ int cm_multi_copy_t(int32_t n, const float *const *src, float *const *dst, const
 int cm_multi_adam_step(int32_t n, float *const *params, float *const *grads, float *const *exp_avg, float *const *exp_avg_sq,
                        const int64_t *sizes, float *norm_ws, float max_norm, float lr, float beta1,
                        float beta2, float eps, int32_t step, void *stream);
+/* The same step for a captured hipGraph that is replayed for SUCCESSIVE optimiser steps (the 10 mini-epochs over one minibatch,
+ * centralized_ma_ppo.py:211-268, are the same launches on the same buffers): the bias-correction factors of step `first + *cursor`
+ * are read from a DEVICE table [table_steps][2] = (1 - beta1^t, sqrt(1 - beta2^t)) indexed by the DEVICE counter `cursor` (the caller
+ * advances it between steps; clamped to the table).  cm_adam_bias_corrections fills a HOST table with exactly the factors
+ * cm_multi_adam_step computes for steps first_step .. first_step + n_steps - 1 (same f64 -> f32 arithmetic: the replayed steps
+ * are bit-identical to eager ones). */
+void cm_adam_bias_corrections(float beta1, float beta2, int32_t first_step, int32_t n_steps, float *table);
+int cm_multi_adam_step_dev(int32_t n, float *const *params, float *const *grads, float *const *exp_avg, float *const *exp_avg_sq,
+                           const int64_t *sizes, float *norm_ws, float max_norm, float lr, float beta1, float beta2, float eps,
+                           const float *bc_table, const int32_t *cursor, int32_t table_steps, void *stream);
+
+/* The critic's loss (comm_base_critic.py:59-89: -Normal(values, std.mean()).log_prob(returns).mean(); values = the per-agent
+ * outputs summed over the team, :110-112; std = exp(clamp(log_std, min)) of gaussian_mlp_module.py:62-188) in one launch, its
+ * gradient in one more.  per_agent [S,N], returns [S], log_std: the DEVICE scalar parameter; has_min = 0 ignores min_log_std.
+ *   forward : out[0] = loss, out[1] = mean_s (returns - values)^2 (read by the backward);  ws: CM_GAUSS_WS_BYTES of DEVICE memory,
+ *             zero before the first use - the launch leaves it zero again (f64 sum of squares + a block counter)
+ *   backward: d_per_agent [S,N] and d_log_std [1] (may be NULL), both times the DEVICE scalar *g (NULL = 1). */
+#define CM_GAUSS_WS_BYTES 16
+int cm_gauss_nll_forward(int64_t S, int32_t N, const float *per_agent, const float *returns, const float *log_std, float min_log_std,
+                         int32_t has_min, float *out, void *ws, void *stream);
+int cm_gauss_nll_backward(int64_t S, int32_t N, const float *per_agent, const float *returns, const float *log_std, float min_log_std,
+                          int32_t has_min, const float *out, const float *g, float *d_per_agent, float *d_log_std, void *stream);
 
 /* tensor_utils.discount_cumsum (garage/misc/tensor_utils.py:7-23) per path over a padded
  * [P,T] batch: f64 recurrence, f32 result, zero past lens[p]. */
