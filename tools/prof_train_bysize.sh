@@ -4,7 +4,7 @@
 set -e
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_bysize -o train -- python3 $ROOT/bench.py --steps 200 --warmup 50 --no-cpu-baseline > $ROOT/gpurun_out/prof_train_bysize.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_bysize -o train -- python3 $ROOT/bench.py --steps 200 --warmup 50 --no-cpu-baseline --no-extra-configs --no-kernel-table > $ROOT/gpurun_out/prof_train_bysize.log 2>&1
 python3 - <<'PY' > $ROOT/gpurun_out/prof_train_bysize.txt
 import csv, glob, collections
 f = glob.glob('/tmp/prof_bysize/**/*kernel_trace.csv', recursive=True)[0]
