@@ -82,9 +82,10 @@ class _UpdateGraphs:
         E = algo._optimization_mini_epochs
         obs = minibatches[0][0]
         if (mode == "0" or distributed or not obs.is_cuda or E < 3
-                or not all(hasattr(o, "begin_device_steps") for o in (algo._optimizer, algo._baseline_optimizer))):
-            return None
-        rows = max(mb[0].shape[0] for mb in minibatches) * T * algo.policy._n_agents
+                or not all(hasattr(o, "begin_device_steps") for o in (algo._optimizer, algo._baseline_optimizer))
+                or not _fused_loss_ok(algo.policy, obs, None, minibatches[0][1], minibatches[0][3])):   # (the framework's Categorical
+            return None                                                                                # validates on the host)
+        rows = max(mb[0].shape[0] for mb in minibatches) * T * getattr(algo.policy, "_n_agents", 1)
         if mode != "1" and rows > cls.MAX_ROWS:
             return None
         # the first optimiser steps of a process go eagerly (first-use set-up inside the library, Adam's moment buffers and norm
@@ -95,48 +96,64 @@ class _UpdateGraphs:
     def __init__(self, algo, n_mb, n_steps, first_epoch):
         self.algo, self.graphs, self.done, self.n_steps, self.first_epoch = algo, [None] * n_mb, 0, n_steps, first_epoch
         self.pool, self.stream = None, None
-        self.armed = False
+        self.armed, self.broken = False, False
 
     def step(self, i, fn):
-        """Step of minibatch i (captured on first use) -> a copy of its gradient-norm output."""
-        if not self.armed:                                   # after mini-epoch 0: the moments exist, the step counts are known
+        """Step of minibatch i: replayed from its graph (captured on first use) -> the step's gradient-norm output.  A capture that
+        fails (an op of a custom net that waits for the host, ...) switches the rest of the epoch back to eager steps."""
+        if self.broken:
+            return fn()
+        if not self.armed:                                   # the moments exist, the step counts are known
             self.algo._optimizer.begin_device_steps(self.n_steps)
             self.algo._baseline_optimizer.begin_device_steps(self.n_steps)
             self.armed = True
         if self.graphs[i] is None:
-            # capture_begin / capture_end directly: torch.cuda.graph() would synchronise the device and empty the allocator's cache
-            # in front of every capture
-            g = torch.cuda.CUDAGraph()
-            cur = torch.cuda.current_stream()
-            if self.stream is None:
-                self.stream = torch.cuda.Stream(device=cur.device)
-            self.stream.wait_stream(cur)
-            # a capture freezes the host's decisions: the weight-pack cache must not answer "fresh" (it would, right after the
-            # epoch's no-grad forward) - the replays run after optimiser steps the host-side version counters never saw
-            for net in (self.algo.policy, self.algo.baseline):
-                if hasattr(net, "_pack_sig"):
-                    net._pack_sig = None
-            with L.capture_guard(), torch.cuda.stream(self.stream):
-                kw = {} if self.pool is None else dict(pool=self.pool)
-                g.capture_begin(capture_error_mode=os.environ.get("COMMARL_CAPTURE_MODE", "thread_local"), **kw)
-                try:
-                    out = fn()
-                finally:
-                    g.capture_end()
-            cur.wait_stream(self.stream)
-            if self.pool is None:
-                self.pool = g.pool()
-            self.graphs[i] = (g, out)
+            try:
+                self.graphs[i] = self._capture(fn)
+            except Exception as e:                           # noqa: BLE001 - whatever the capture tripped over, the step itself is fine
+                import warnings
+                warnings.warn(f"PPO update: hipGraph capture of the optimiser step failed ({type(e).__name__}: {e}); eager steps from here")
+                torch.cuda.synchronize()
+                self.close()
+                self.broken = True
+                return fn()
         g, out = self.graphs[i]
         g.replay()
         self.done += 1
         return out
 
+    def _capture(self, fn):
+        # capture_begin / capture_end directly: torch.cuda.graph() would synchronise the device and empty the allocator's cache
+        # in front of every capture
+        g = torch.cuda.CUDAGraph()
+        cur = torch.cuda.current_stream()
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(device=cur.device)
+        self.stream.wait_stream(cur)
+        # a capture freezes the host's decisions: the weight-pack cache must not answer "fresh" (it would, right after the
+        # epoch's no-grad forward) - the replays run after optimiser steps the host-side version counters never saw
+        for net in (self.algo.policy, self.algo.baseline):
+            if hasattr(net, "_pack_sig"):
+                net._pack_sig = None
+        with L.capture_guard(), torch.cuda.stream(self.stream):
+            kw = {} if self.pool is None else dict(pool=self.pool)
+            g.capture_begin(capture_error_mode=os.environ.get("COMMARL_CAPTURE_MODE", "thread_local"), **kw)
+            try:
+                out = fn()
+            finally:
+                g.capture_end()
+        cur.wait_stream(self.stream)
+        if self.pool is None:
+            self.pool = g.pool()
+        return g, out
+
     def close(self):
+        """Book the replayed steps into the optimisers' host state and drop the graphs (idempotent)."""
         if self.armed:
             self.algo._optimizer.end_device_steps(self.done)
             self.algo._baseline_optimizer.end_device_steps(self.done)
-        self.graphs = None
+            self.armed, self.done = False, 0
+        self.graphs = [None] * len(self.graphs) if self.graphs is not None else None
 
 
 class CentralizedMAPPO:
@@ -529,16 +546,18 @@ class CentralizedMAPPO:
         # other weights: for the small (launch-bound) batches of the reference's own configuration each minibatch's step is
         # captured into a hipGraph in mini-epoch 1 and replayed from then on (_UpdateGraphs).
         graphs = _UpdateGraphs.maybe(self, minibatches, T, distributed)
-        for mini_epoch in range(self._optimization_mini_epochs):
-            for i, mb in enumerate(minibatches):
-                if graphs is not None and mini_epoch >= graphs.first_epoch:
-                    gn = graphs.step(i, lambda mb=mb, i=i: one_step(mb, n_crits[i]))
-                else:
-                    gn = one_step(mb, n_crits[i])
-                    self._eager_stepped = True
-                grad_norm.append(gn.clone() if torch.is_tensor(gn) else gn)
-        if graphs is not None:
-            graphs.close()
+        try:
+            for mini_epoch in range(self._optimization_mini_epochs):
+                for i, mb in enumerate(minibatches):
+                    if graphs is not None and mini_epoch >= graphs.first_epoch:
+                        gn = graphs.step(i, lambda mb=mb, i=i: one_step(mb, n_crits[i]))
+                    else:
+                        gn = one_step(mb, n_crits[i])
+                        self._eager_stepped = True
+                    grad_norm.append(gn.clone() if torch.is_tensor(gn) else gn)
+        finally:
+            if graphs is not None:                           # the optimisers leave the device-step mode whatever happened
+                graphs.close()
         torch.cuda.synchronize(obs.device)
         epoch_time = time.time() - t_opt
         self.policy.sync_weights()
