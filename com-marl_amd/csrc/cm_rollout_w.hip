@@ -14,7 +14,7 @@ bool policy_w_enabled();                                 // cm_policy_w.hip
 
 // diagnostic (COMMARL_ENV_STOP=-2): shader clocks of workgroup 0 / thread 0, summed over the launch's steps: [0] steps, [1] policy
 // tile, [2] env phase, [3] weight staging
-static __device__ unsigned long long g_w_probe[4];
+static __device__ unsigned long long g_w_probe[5];
 
 // ---- teams of 4, wave-owned rows (cm_policy_w_dev.h): a workgroup = 16 envs = four waves, ONE per SIMD; a wave carries its four
 // envs through policy forward, sample AND env step by itself - the actions go through LDS words only that wave touches, the env
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     mw::ResidentW res;
     res.fetch<LHOPS>(w, thread_x() & 63);
     __syncthreads();                                                     // the only workgroup barrier of the launch
-    if (probe) { g_w_probe[3] = __builtin_amdgcn_s_memtime() - t_in; g_w_probe[0] = g_w_probe[1] = g_w_probe[2] = 0; }
+    if (probe) { g_w_probe[3] = __builtin_amdgcn_s_memtime() - t_in; g_w_probe[0] = g_w_probe[1] = g_w_probe[2] = g_w_probe[4] = 0; }
     const int envs = FULLWG ? mw::WG_ENVS : min(mw::WG_ENVS, a.S - (int)blockIdx.x * mw::WG_ENVS);
     for (int t = 0; t < c.n_steps; ++t) {
         asm volatile("" ::: "memory");                                   // keep each step's loads inside the step
@@ -82,9 +82,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         // step t + 1 reads what this WAVE wrote (observation, masks, env state): its stores are performed before its next loads;
         // the CU's vector L1 is write-through and shared, so workgroup scope needs no cache maintenance (as rollout_chunk_kernel)
+        const unsigned long long tf = probe ? __builtin_amdgcn_s_memtime() : 0ull;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        if (probe) { const unsigned long long t2 = __builtin_amdgcn_s_memtime(); g_w_probe[0] += 1; g_w_probe[1] += t1 - t0; g_w_probe[2] += t2 - t1; }
+        if (probe) { const unsigned long long t2 = __builtin_amdgcn_s_memtime(); g_w_probe[0] += 1; g_w_probe[1] += t1 - t0; g_w_probe[2] += t2 - t1; g_w_probe[4] += t2 - tf; }
     }
 }
 
@@ -135,9 +136,10 @@ int launch_rollout_w(mf::FwdArgs a, const cm_policy_weights *w, const void *w_pa
         }
     }
     if (d.stop == -2) {
-        unsigned long long hp[4];
+        unsigned long long hp[5];
         if (hipStreamSynchronize((hipStream_t)stream) == hipSuccess && hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_w_probe), sizeof(hp)) == hipSuccess && hp[0])
-            fprintf(stderr, "[rollout_w probe] steps=%llu staging=%llu clk; per step: policy=%llu env=%llu clk\n", hp[0], hp[3], hp[1] / hp[0], hp[2] / hp[0]);
+            fprintf(stderr, "[rollout_w probe] steps=%llu staging=%llu clk; per step: policy=%llu env=%llu clk (of which the closing fence %llu)\n", hp[0],
+                    hp[3], hp[1] / hp[0], hp[2] / hp[0], hp[4] / hp[0]);
     }
     return CM_OK;
 }
