@@ -224,11 +224,16 @@ __device__ __forceinline__ void do_reset(const EnvDev &p, const Lds l, const Rng
 // the headline shape); a caller that knows the step early passes them in registers instead: lane s of an env's group holds
 // row[s] and col[s] (grid side <= lanes per env) and the element fetches its entry with a lane shuffle.
 struct ObsTabs { bool held; float row, col, step; };
+// Carried rollout (cm_rollout_w.hip): inside a multi-step launch a wave's envs hand their state from step to step through LDS
+// and registers instead of through the global arrays (which are still written every step): the next step loads nothing a store
+// of this launch produced, so no fence stands between two steps and the trajectory stores drain under the next policy forward.
+constexpr int OBS_COPY_STRIDE = 24;                      // floats per observation row of the LDS copy (d <= 24)
+struct EnvCarry { int step_count, succ, done; };
 
 template <int SCEN, int LPE>
 __device__ __forceinline__ void emit(const EnvDev &p, const Lds l, const Rng rng, const cm_rng_tape &tape,
                                      const cm_step_out &out, int b, const Grp<LPE> g, int step_count, int slot,
-                                     const ObsTabs tabs = ObsTabs{ false, 0.0f, 0.0f, 0.0f }) {
+                                     const ObsTabs tabs = ObsTabs{ false, 0.0f, 0.0f, 0.0f }, int obs_copy = -1) {
     const int S = p.S, N = p.N, M = p.M, R = p.R, W = p.W, d = p.d, WW = W * W, sl = g.sl;
     const float rcp_d = p.rcp_d, rcp_W = p.rcp_W, rcp_N = p.rcp_N, rcp_WW = p.rcp_WW, rcp_NN = p.rcp_NN;
     // ---- observations [N*d], lanes stride the flattened row -> coalesced stores ----
@@ -259,6 +264,8 @@ __device__ __forceinline__ void emit(const EnvDev &p, const Lds l, const Rng rng
                 } else v = f == 3 * WW ? vrow : (f == 3 * WW + 1 ? vcol : tabs.step);      // (:206)
             }
             if (on) o[k] = v;
+            // the persistent rollout keeps a copy for its next policy forward (rows of OBS_COPY_STRIDE floats in the env's LDS area)
+            if (on && obs_copy >= 0) reinterpret_cast<float *>(smem + obs_copy)[i * OBS_COPY_STRIDE + f] = v;
         }
     } else if (out.obs) {
         float *o = out.obs + (size_t)b * N * d;
@@ -769,6 +776,28 @@ __device__ __forceinline__ bool env_stage(const EnvDev &p, const EnvPre &e, cons
     return bad;
 }
 
+// The next step's EnvPre from what the step just taken left behind: positions / alive flags in the env's LDS arrays (after the
+// auto-reset), the scalars in `carry`; the lane's table entries (row, col, reward terms) are launch constants and stay.  What
+// env_prefetch would have loaded from the global state arrays - written by this very wave a moment ago - is never read.
+//   agent_condition: do_reset re-arms every agent of a finished env (:152), nothing else changes it inside a launch
+//   rng_step       : advanced by one per step (env_body: p.rng_step[b] = rng.step + 1)
+template <int SCEN, int LPE>
+__device__ __forceinline__ EnvPre env_pre_carry(const EnvDev &p, const EnvPre &prev, const EnvCarry &carry, int grp, int lds_base) {
+    const int sl = thread_x() % LPE;
+    const Lds l = make_lds(p.S, p.N, p.M, lds_base + p.lds_env * grp, p.status);
+    EnvPre e = prev;
+    e.step_count_in = carry.step_count;
+    e.succ = carry.succ;
+    e.rng_step = prev.rng_step + 1u;
+    const int ia = sl < p.N ? sl : 0, ip = sl < p.M ? sl : 0;
+    e.ax = AR(l, ia); e.ay = AC(l, ia);
+    e.cond = carry.done ? 1 : prev.cond;
+    e.px = PR(l, ip); e.py = PC(l, ip); e.alive = ALV(l, ip);
+    const int sc = e.step_count_in + 1;
+    e.t_step = p.lut_step[sc <= p.max_steps ? sc : p.max_steps];
+    return e;
+}
+
 template <int SCEN, int LPE>
 __device__ __forceinline__ void env_body(const EnvDev &p, const int32_t *__restrict__ actions, const int32_t *act_lds,
                                          const cm_rng_tape &tape, const cm_step_out &out, int reset_only, int grp, int b_raw,
@@ -778,7 +807,8 @@ __device__ __forceinline__ void env_body(const EnvDev &p, const int32_t *__restr
                                          float pre_t_row = 0.0f, float pre_t_col = 0.0f, float pre_t_step0 = 0.0f,
                                          float pre_t_step = 0.0f, double pre_t_rew = 0.0,
                                          bool pre_bad = false,
-                                         bool all_valid = false /* the caller vouches: every group has an env of its own below p.B */) {
+                                         bool all_valid = false /* the caller vouches: every group has an env of its own below p.B */,
+                                         EnvCarry *carry = nullptr, int obs_copy = -1) {
     Grp<LPE> g;
     const int tx = thread_x();
     g.sub = (tx & (WAVE - 1)) / LPE; g.sl = tx % LPE;
@@ -1117,7 +1147,8 @@ __device__ __forceinline__ void env_body(const EnvDev &p, const int32_t *__restr
     // wide kernel: the emission (order-independent, the bulk of the instructions for large teams) is done by all the
     // workgroup's waves after this wave has left the state in LDS; hand over (step count, slot, Philox step)
     if (defer) { if (sl == 0) { defer[1] = step_count; defer[2] = done ? 1 : 0; defer[3] = (int)rng.step; defer[0] = 1; } return; }
-    emit<SCEN, LPE>(p, l, rng, tape, o, b, g, step_count, done ? 1 : 0, ObsTabs{ tabs_held, t_row, t_col, done ? t_step0 : t_step });
+    if (carry) { carry->step_count = step_count; carry->succ = succ; carry->done = done; }
+    emit<SCEN, LPE>(p, l, rng, tape, o, b, g, step_count, done ? 1 : 0, ObsTabs{ tabs_held, t_row, t_col, done ? t_step0 : t_step }, obs_copy);
     ENV_PROBE(9);
 }
 

@@ -246,9 +246,11 @@ struct ResidentW {
 // ---- one wave's tile: rows [16 * wave, 16 * wave + 16) of workgroup blk.  No workgroup barrier: everything is the wave's own. ----
 // lds: the staged image.  act_lds (may be null): sampled actions of the workgroup's 64 rows for the env phase of the fused step.
 // A ragged last workgroup (S % 16 != 0) computes on zero rows and stores nothing for them.
-template <int LHOPS>
+// OBS_LDS: the observation rows come from an LDS copy the caller keeps (byte offset `obs_row` of this lane's row c, rows of
+// at least 24 floats with zeros behind the d real entries) instead of from a.obs - the carried rollout (cm_rollout_w.hip).
+template <int LHOPS, bool OBS_LDS = false>
 __device__ __forceinline__ void policy_tile_w(const FwdArgs &a, int n_act, const ResidentW &res, const unsigned char *lds, int blk,
-                                              int32_t *act_lds) {
+                                              int32_t *act_lds, int obs_row = 0) {
     static_assert(LHOPS >= 1 && LHOPS <= 2, "wave-owned forward: one or two hops");
     const int tid = thread_x(), wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
     constexpr PackW pk = pack_w(LHOPS);
@@ -267,9 +269,17 @@ __device__ __forceinline__ void policy_tile_w(const FwdArgs &a, int n_act, const
     Act<1> xo;
     {
         float ov[8];
+        if constexpr (OBS_LDS) {
+            const float4 *src = reinterpret_cast<const float4 *>(lds + obs_row + 32 * (g < 3 ? g : 0));
+            const float4 v0 = src[0], v1 = src[1];
+            const float vv[8] = { v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w };
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ov[e] = (rv && g < 3) ? vv[e] : 0.0f;
+        } else {
         const float *src = a.obs + (rv ? grow : 0) * a.d;       // every load is in range: no predicated (branchy) loads
 #pragma unroll
         for (int e = 0; e < 8; ++e) { const int k = 8 * g + e; const float v = src[k < a.d ? k : 0]; ov[e] = (rv && k < a.d) ? v : 0.0f; }
+        }
         h16 h[8], l[8];
         split_stage<8>(ov, h, l);
 #pragma unroll

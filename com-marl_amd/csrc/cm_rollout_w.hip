@@ -26,8 +26,13 @@ static __device__ unsigned long long g_w_probe[5];
 // RNG tape - test-only, single-step launches - is a compile-time variant.
 struct StridesW { int n_steps, obs, actions, probs, attn, reward, reward_f64, done, details, dist_adj, channels, prey_alive, success, path_len; };
 
-template <int LHOPS, bool PRE, bool FULLWG, bool TAPE>
+// CARRY (PRE builds, constant adjacency, no channel model, no tape): a wave's envs hand observation and state from step to step
+// through LDS and registers (EnvCarry, env_pre_carry, the observation copy in the env area's unused claim table); no load of a
+// step depends on a store of the launch, so the fence between two steps goes and the trajectory stores of step t drain under
+// the policy forward of step t + 1.
+template <int LHOPS, bool PRE, bool FULLWG, bool TAPE, bool CARRY = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rollout_w_kernel(mf::FwdArgs a, mw::WeightsW w, EnvDev p, cm_rng_tape tape_arg, cm_step_out out, StridesW c) {
+    static_assert(!CARRY || (PRE && !TAPE), "the carried form is the prefetching, tape-less build");
     const cm_rng_tape tape = TAPE ? tape_arg : cm_rng_tape{};
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_w[];
     constexpr int LPE = 16;
@@ -41,6 +46,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     __syncthreads();                                                     // the only workgroup barrier of the launch
     if (probe) { g_w_probe[3] = __builtin_amdgcn_s_memtime() - t_in; g_w_probe[0] = g_w_probe[1] = g_w_probe[2] = g_w_probe[4] = 0; }
     const int envs = FULLWG ? mw::WG_ENVS : min(mw::WG_ENVS, a.S - (int)blockIdx.x * mw::WG_ENVS);
+    EnvPre pre{};
+    int obs_row = 0, obs_env = -1;                                       // LDS copy: this lane's row (policy) / this group's env (emission)
+    if constexpr (CARRY) {
+        const int tx = thread_x(), grp = tx / LPE, lane = tx & 63, cc = lane & 15;
+        const bool live = FULLWG || grp < envs;
+        const Lds l0 = make_lds(p.S, p.N, p.M, ENV_BASE + p.lds_env * grp, p.status);
+        obs_env = l0.win;                                                // teams of 4 never run agents_parallel: its claim table is free
+        const int env_l = (tx >> 6) * 4 + (cc >> 2);                     // env of the policy's row c
+        obs_row = make_lds(p.S, p.N, p.M, ENV_BASE + p.lds_env * env_l, p.status).win + (cc & 3) * OBS_COPY_STRIDE * 4;
+        // step 0: the observation of slot 0 into the copy (rows of this group's env; zeros behind the d entries), the env
+        // state from the global arrays - the only loads of the launch that read what an earlier launch wrote
+        float *oc = reinterpret_cast<float *>(lds_w + obs_env);
+        const int b0 = blockIdx.x * mw::WG_ENVS + (live ? grp : 0);
+        const bool ok = live && b0 < a.S;
+        for (int k = tx % LPE; k < 4 * OBS_COPY_STRIDE; k += LPE) {
+            const int i = k / OBS_COPY_STRIDE, f = k - i * OBS_COPY_STRIDE;
+            oc[k] = (ok && f < a.d) ? a.obs[((size_t)b0 * 4 + i) * a.d + f] : 0.0f;
+        }
+        pre = env_prefetch<CM_PP, LPE>(p, b0, live);
+    }
     for (int t = 0; t < c.n_steps; ++t) {
         asm volatile("" ::: "memory");                                   // keep each step's loads inside the step
         const int tx = thread_x(), grp = tx / LPE;
@@ -55,10 +80,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         at.actions = a.actions ? a.actions + (size_t)t * c.actions : nullptr;
         at.probs = a.probs ? a.probs + (size_t)t * c.probs : nullptr;
         at.attn = a.attn ? a.attn + (size_t)t * c.attn : nullptr;
-        EnvPre pre{};
         const unsigned long long t0 = probe ? __builtin_amdgcn_s_memtime() : 0ull;
-        if constexpr (PRE) pre = env_prefetch<CM_PP, LPE>(p, b_raw, live);   // env state requested in front of the policy forward
-        mw::policy_tile_w<LHOPS>(at, w.n_act, res, lds_w, blockIdx.x, act);
+        if constexpr (PRE && !CARRY) pre = env_prefetch<CM_PP, LPE>(p, b_raw, live);   // env state requested in front of the policy forward
+        mw::policy_tile_w<LHOPS, CARRY>(at, w.n_act, res, lds_w, blockIdx.x, act, obs_row);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // this wave's action words are in LDS
         const unsigned long long t1 = probe ? __builtin_amdgcn_s_memtime() : 0ull;
         cm_step_out ot = out;
@@ -74,7 +98,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (ot.path_len) ot.path_len += (size_t)t * c.path_len;
         if (env_wave) {
             const int32_t *my_act = act + (live ? grp : 0) * 4;
-            if constexpr (PRE) {
+            if constexpr (CARRY) {
+                const bool bad = env_stage<CM_PP, LPE>(p, pre, my_act, grp, ENV_BASE);
+                EnvCarry carry{ pre.step_count_in, pre.succ, 0 };
+                env_body<CM_PP, LPE>(p, nullptr, my_act, tape, ot, 0, grp, b_raw, live, ENV_BASE, nullptr, true, pre.rng_step, pre.step_count_in,
+                                     pre.succ, pre.t_row, pre.t_col, pre.t_step0, pre.t_step, pre.t_rew, bad, FULLWG, &carry, obs_env);
+                pre = env_pre_carry<CM_PP, LPE>(p, pre, carry, grp, ENV_BASE);
+            } else if constexpr (PRE) {
                 const bool bad = env_stage<CM_PP, LPE>(p, pre, my_act, grp, ENV_BASE);
                 env_body<CM_PP, LPE>(p, nullptr, my_act, tape, ot, 0, grp, b_raw, live, ENV_BASE, nullptr, true, pre.rng_step, pre.step_count_in,
                                      pre.succ, pre.t_row, pre.t_col, pre.t_step0, pre.t_step, pre.t_rew, bad, FULLWG);
@@ -83,8 +113,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // step t + 1 reads what this WAVE wrote (observation, masks, env state): its stores are performed before its next loads;
         // the CU's vector L1 is write-through and shared, so workgroup scope needs no cache maintenance (as rollout_chunk_kernel)
         const unsigned long long tf = probe ? __builtin_amdgcn_s_memtime() : 0ull;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if constexpr (!CARRY) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
         if (probe) { const unsigned long long t2 = __builtin_amdgcn_s_memtime(); g_w_probe[0] += 1; g_w_probe[1] += t1 - t0; g_w_probe[2] += t2 - t1; g_w_probe[4] += t2 - tf; }
     }
 }
@@ -112,17 +144,23 @@ int launch_rollout_w(mf::FwdArgs a, const cm_policy_weights *w, const void *w_pa
     const int blocks = (a.S + mw::WG_ENVS - 1) / mw::WG_ENVS;
     static const int pre_flag = [] { const char *e = getenv("COMMARL_ENV_PREFETCH"); return (e && e[0] == '0') ? 0 : 1; }();
     const bool pre = pre_flag && env_prefetch_ok<CM_PP, 16>(d), full = a.S % mw::WG_ENVS == 0;
-#define CM_RW(LH, PR, FU, TP)                                                                                                   \
+    // carried form (state and observation from step to step inside the wave, no fence between steps): multi-step launches on
+    // a constant adjacency without a channel model; the observation copy needs 4 rows x 24 floats in the env area's claim table
+    static const int carry_flag = [] { const char *e = getenv("COMMARL_ROLLOUT_CARRY"); return (e && e[0] == '0') ? 0 : 1; }();
+    const bool carry = carry_flag && pre && !use_tape && c.n_steps > 1 && d.adj_const && d.ch_const && !a.adj && !a.chan &&
+                       a.d <= OBS_COPY_STRIDE && 4 * d.S * d.S >= 4 * OBS_COPY_STRIDE * 4;
+#define CM_RW(LH, PR, FU, TP, CA)                                                                                               \
     do {                                                                                                                        \
         static unsigned long long done = 0;                                                                                     \
         if (cm::dev_first(done))                                                                                                \
-            CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_w_kernel<LH, PR, FU, TP>),                       \
+            CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_w_kernel<LH, PR, FU, TP, CA>),                   \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                                \
-        hipLaunchKernelGGL((rollout_w_kernel<LH, PR, FU, TP>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, a, ww, d, t, out, c); \
+        hipLaunchKernelGGL((rollout_w_kernel<LH, PR, FU, TP, CA>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, a, ww, d, t, out, c); \
     } while (0)
-#define CM_RW2(LH) do { if (use_tape) CM_RW(LH, false, false, true);                                                            \
-                        else if (pre) { if (full) CM_RW(LH, true, true, false); else CM_RW(LH, true, false, false); }           \
-                        else { if (full) CM_RW(LH, false, true, false); else CM_RW(LH, false, false, false); } } while (0)
+#define CM_RW2(LH) do { if (use_tape) CM_RW(LH, false, false, true, false);                                                     \
+                        else if (carry) { if (full) CM_RW(LH, true, true, false, true); else CM_RW(LH, true, false, false, true); } \
+                        else if (pre) { if (full) CM_RW(LH, true, true, false, false); else CM_RW(LH, true, false, false, false); } \
+                        else { if (full) CM_RW(LH, false, true, false, false); else CM_RW(LH, false, false, false, false); } } while (0)
     if (d.L == 1) CM_RW2(1); else CM_RW2(2);
 #undef CM_RW2
 #undef CM_RW

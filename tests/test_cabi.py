@@ -177,7 +177,7 @@ def test_wave_owned_rollout_kernels_use_no_flat_or_scratch_addressing(tmp_path):
         seen += 1
         assert re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1) == "0", name
         assert re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1) == "0", name
-    assert seen == 10, seen                                               # 1 / 2 hops x (env prefetch on / off x full / ragged workgroups + the tape variant)
+    assert seen == 14, seen     # 1 / 2 hops x (env prefetch on / off x full / ragged workgroups + the tape variant + carried full / ragged)
     for m in re.finditer(r"^(_ZN2cm16rollout_w_kernel\S+):\n(.*?)\n\.Lfunc_end", asm, re.M | re.S):
         assert not re.search(r"^\s+(flat_(load|store|atomic)|scratch_)", m.group(2), re.M), m.group(1)
         assert len(re.findall(r"^\s+s_barrier", m.group(2), re.M)) == 1, "one workgroup barrier per launch (behind the weight staging)"

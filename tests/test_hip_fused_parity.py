@@ -79,12 +79,14 @@ def test_fused_step_is_bit_identical_to_two_launches(shape, greedy):
             np.testing.assert_array_equal(a[k], b[k], err_msg=k)
 
 
+@pytest.mark.parametrize("chunked", [False, True], ids=["steps", "chunks"])
 @pytest.mark.parametrize("shape", ["pp_map10", "pp_map10_full"])
-def test_fused_step_with_agent_faults(shape):
+def test_fused_step_with_agent_faults(shape, chunked):
     """Faulty agents (condition 0: the move is computed, counted and not applied) through the fused step's own staging of
-    the env state - ragged and full workgroups - against the two-launch path."""
+    the env state - ragged and full workgroups - against the two-launch path; as single-step launches and as multi-step
+    launches, where the condition travels from step to step inside the wave (EnvCarry) and an auto-reset re-arms it."""
     import torch
-    a, used = _run(torch, shape, True, False, faults=True)
+    a, used = _run(torch, shape, True, False, faults=True, chunked=chunked)
     assert used is True
     b, _ = _run(torch, shape, False, False, faults=True)
     for k in sorted(b):
