@@ -101,6 +101,10 @@ _SIGNATURES = {
     "cm_rollout_chunk": (C.c_int, [C.c_void_p, C.POINTER(PolicyWeights), C.c_int32, C.POINTER(ChunkStrides), C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_uint32, C.c_void_p, C.c_int32,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(StepOut), C.c_void_p]),
+    "cm_rollout_chunk_tail": (C.c_int, [C.c_void_p, C.POINTER(PolicyWeights), C.c_int32, C.POINTER(ChunkStrides), C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_uint32, C.c_void_p, C.c_int32,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(StepOut), C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]),
     "cm_policy_pack_bytes": (C.c_size_t, [C.POINTER(PolicyWeights)]),
     "cm_policy_pack": (C.c_int, [C.POINTER(PolicyWeights), C.c_void_p, C.c_void_p]),
     "cm_policy_pack_sections": (C.c_int, [C.POINTER(PolicyWeights), C.c_void_p, C.c_int32, C.c_void_p]),

@@ -183,7 +183,7 @@ extern "C" int cm_env_create(const cm_env_cfg *cfg, cm_env_t *out) {
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~size_t(255); return o; };
     const size_t o_ap = take(B * N * sizeof(int2)), o_pp = take(B * (M ? M : 1) * sizeof(int2)), o_al = take(B * (M ? M : 1)),
                  o_vis = take(B * S * ((S + 31) / 32) * 4), o_sc = take(B * 4), o_tc = take(B * 4), o_su = take(B * 4),
-                 o_ge = take(c.channel == CM_CH_GE ? B * N * N : 1), o_rs = take(B * 4), o_ac = take(B * N), o_st = take(4),
+                 o_ge = take(c.channel == CM_CH_GE ? B * N * N : 1), o_rs = take(B * 4), o_ac = take(B * N), o_st = take(4), o_tk = take(4),
                  o_bg = take((size_t)S * S), o_lr = take(S * 4), o_lc = take(S * 4), o_ls = take((c.max_steps + 1) * 4),
                  o_rl = take(rew_lut.size() * 8);
     h->arena_bytes = off;
@@ -197,6 +197,7 @@ extern "C" int cm_env_create(const cm_env_cfg *cfg, cm_env_t *out) {
     d.success = (int32_t *)(base + o_su); d.ge_state = (uint8_t *)(base + o_ge); d.rng_step = (uint32_t *)(base + o_rs);
     d.agent_cond = (uint8_t *)(base + o_ac);
     d.status = (int32_t *)(base + o_st);
+    d.tail_ticket = (unsigned int *)(base + o_tk);
     d.base_grid = (const uint8_t *)(base + o_bg); d.lut_row = (const float *)(base + o_lr); d.lut_col = (const float *)(base + o_lc);
     d.lut_step = (const float *)(base + o_ls);
     d.rew_lut = (const double *)(base + o_rl);

@@ -288,3 +288,30 @@ extern "C" int cm_rollout_chunk(cm_env_t h, const cm_policy_weights *w, int32_t 
     return rollout_impl(h, w, obs, nullptr, dist_adj, channels, seed, env_id_offset, policy_step, policy_step_base, greedy, actions,
                         probs, attn, nullptr, out, stream, &c);
 }
+
+extern "C" int cm_rollout_chunk_tail(cm_env_t h, const cm_policy_weights *w, int32_t n_steps, const cm_chunk_strides *st,
+                                     const float *obs, const float *dist_adj, const float *channels, uint64_t seed,
+                                     int32_t env_id_offset, uint32_t policy_step, uint32_t *policy_step_base, int32_t greedy,
+                                     int32_t *actions, float *probs, float *attn, const cm_step_out *out, float *obs_next,
+                                     float *dist_adj_next, float *channels_next, void *stream) {
+    if (!st) return set_error(CM_ERR_ARG, "cm_rollout_chunk_tail: null strides");
+    if (n_steps < 1) return set_error(CM_ERR_ARG, "cm_rollout_chunk_tail: at least one step");
+    if (!h || !out || !out->obs || !obs_next || !policy_step_base) return set_error(CM_ERR_ARG, "cm_rollout_chunk_tail: null argument");
+    if (h->cfg.rng_mode == CM_RNG_TAPE) return set_error(CM_ERR_ARG, "cm_rollout_chunk_tail: tape mode steps one launch at a time");
+    static const int stagger = [] { const char *e = getenv("COMMARL_CHUNK_STAGGER"); return e ? atoi(e) : 0; }();
+    static const bool fold = [] { const char *e = getenv("COMMARL_FOLD_TAIL"); return !(e && e[0] == '0'); }();
+    int folded = 0;
+    ChunkArgs c{ n_steps, stagger, st->obs, st->actions, st->probs, st->attn, st->reward, st->reward_f64, st->done, st->details,
+                 st->dist_adj, st->channels, st->prey_alive, st->success, st->path_len };
+    if (fold) { c.tail_obs = obs_next; c.tail_base = policy_step_base; c.tail_folded = &folded; }
+    const int rc = rollout_impl(h, w, obs, nullptr, dist_adj, channels, seed, env_id_offset, policy_step, policy_step_base, greedy, actions,
+                                probs, attn, nullptr, out, stream, &c);
+    if (rc != CM_OK || folded) return rc;
+    const EnvDev &d = h->dev;
+    const size_t last = (size_t)(n_steps - 1);
+    const bool adj = out->dist_adj && dist_adj_next, ch = out->channels && channels_next;
+    return cm_chunk_tail(policy_step_base, (uint32_t)n_steps, out->obs + last * st->obs, obs_next, (size_t)d.B * d.N * d.d * sizeof(float),
+                         adj ? out->dist_adj + last * st->dist_adj : nullptr, adj ? dist_adj_next : nullptr,
+                         adj ? (size_t)d.B * d.N * d.N * sizeof(float) : 0, ch ? out->channels + last * st->channels : nullptr,
+                         ch ? channels_next : nullptr, ch ? (size_t)d.B * d.L * d.N * d.N * sizeof(float) : 0, stream);
+}

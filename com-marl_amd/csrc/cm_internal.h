@@ -75,6 +75,7 @@ struct EnvDev {
     uint32_t *rng_step;       // [B]
     uint8_t *agent_cond;      // [B,N] PP agent_condition (predator_prey.py:74,152,258): 0 = the agent cannot move
     int32_t *status;          // [1] first kernel-side error
+    unsigned int *tail_ticket;  // [1] zero at rest: waves that finished a chunk whose tail is folded into the kernel (cm_rollout_w.hip)
     // read-only tables
     const uint8_t *base_grid; // [S*S] CO walls (0 empty / 3 wall)
     const float *lut_row;     // [S]   obs row coordinate
@@ -100,6 +101,11 @@ struct ChunkArgs {
     int n_steps;
     int stagger;              // late start of the second half of the grid, in units of s_sleep 32 (~2048 clocks)
     long long obs, actions, probs, attn, reward, reward_f64, done, details, dist_adj, channels, prey_alive, success, path_len;
+    // cm_rollout_chunk_tail: the tail the caller wants behind the chunk - the last step's observation into `tail_obs` (slot 0) and
+    // *tail_base += n_steps.  A kernel that does it itself sets *tail_folded (host) to 1; otherwise the entry point launches cm_chunk_tail.
+    float *tail_obs = nullptr;
+    uint32_t *tail_base = nullptr;
+    int *tail_folded = nullptr;
 };
 
 int check_tape(const cm_env *h, const cm_rng_tape *tape, bool is_reset);   // cm_env.hip: tape pointers the config needs

@@ -24,6 +24,9 @@ static __device__ unsigned long long g_w_probe[5];
 // Scalar registers are the scarce resource of this kernel (every kernel argument lives in SGPRs for the whole step loop; what does not
 // fit is spilled to VGPR lanes and comes back through v_readlane): the per-step strides travel as 32-bit element counts and the
 // RNG tape - test-only, single-step launches - is a compile-time variant.
+// folded chunk tail (CARRY builds): after its last step a wave writes its envs' next observation into slot 0 and takes a ticket;
+// the wave that takes the last one advances the sampler's Philox base - every other wave has read it for the last time
+struct TailW { float *obs_dst; uint32_t *base; unsigned int *ticket; int on; };
 struct StridesW { int n_steps, obs, actions, probs, attn, reward, reward_f64, done, details, dist_adj, channels, prey_alive, success, path_len; };
 
 // CARRY (PRE builds, constant adjacency, no channel model, no tape): a wave's envs hand observation and state from step to step
@@ -31,7 +34,7 @@ struct StridesW { int n_steps, obs, actions, probs, attn, reward, reward_f64, do
 // step depends on a store of the launch, so the fence between two steps goes and the trajectory stores of step t drain under
 // the policy forward of step t + 1.
 template <int LHOPS, bool PRE, bool FULLWG, bool TAPE, bool CARRY = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rollout_w_kernel(mf::FwdArgs a, mw::WeightsW w, EnvDev p, cm_rng_tape tape_arg, cm_step_out out, StridesW c) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rollout_w_kernel(mf::FwdArgs a, mw::WeightsW w, EnvDev p, cm_rng_tape tape_arg, cm_step_out out, StridesW c, TailW tl) {
     static_assert(!CARRY || (PRE && !TAPE), "the carried form is the prefetching, tape-less build");
     const cm_rng_tape tape = TAPE ? tape_arg : cm_rng_tape{};
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_w[];
@@ -119,6 +122,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         if (probe) { const unsigned long long t2 = __builtin_amdgcn_s_memtime(); g_w_probe[0] += 1; g_w_probe[1] += t1 - t0; g_w_probe[2] += t2 - t1; g_w_probe[4] += t2 - tf; }
     }
+    if constexpr (CARRY) {
+        if (tl.on) {                                                     // `obses = next_obses` + the counter advance (cm_chunk_tail) in here
+            const int tx = thread_x(), grp = tx / LPE, sl = tx % LPE;
+            const int b0 = blockIdx.x * mw::WG_ENVS + grp;
+            if ((FULLWG || grp < envs) && b0 < a.S) {
+                const float *oc = reinterpret_cast<const float *>(lds_w + obs_env);
+                float *dst = tl.obs_dst + (size_t)b0 * 4 * a.d;
+                const float rcp_d = p.rcp_d;
+                for (int k = sl; k < 4 * a.d; k += LPE) { const int i = fdiv(k, a.d, rcp_d), f = k - i * a.d; dst[k] = oc[i * OBS_COPY_STRIDE + f]; }
+            }
+            if ((tx & 63) == 0) {
+                const unsigned int last = gridDim.x * (blockDim.x >> 6) - 1;
+                if (atomicAdd(tl.ticket, 1u) == last) { *tl.base += (uint32_t)c.n_steps; *tl.ticket = 0u; }
+            }
+        }
+    }
 }
 
 bool shape_ok_rollout_w(int N, int d, int L, int n_act) { return policy_w_enabled() && mw::shape_ok_w(N, d, L, n_act); }
@@ -149,13 +168,18 @@ int launch_rollout_w(mf::FwdArgs a, const cm_policy_weights *w, const void *w_pa
     static const int carry_flag = [] { const char *e = getenv("COMMARL_ROLLOUT_CARRY"); return (e && e[0] == '0') ? 0 : 1; }();
     const bool carry = carry_flag && pre && !use_tape && c.n_steps > 1 && d.adj_const && d.ch_const && !a.adj && !a.chan &&
                        a.d <= OBS_COPY_STRIDE && 4 * d.S * d.S >= 4 * OBS_COPY_STRIDE * 4;
+    TailW tl{};
+    if (carry && chunk && chunk->tail_obs && chunk->tail_base && chunk->tail_folded) {
+        tl = TailW{ chunk->tail_obs, chunk->tail_base, d.tail_ticket, 1 };
+        *chunk->tail_folded = 1;
+    }
 #define CM_RW(LH, PR, FU, TP, CA)                                                                                               \
     do {                                                                                                                        \
         static unsigned long long done = 0;                                                                                     \
         if (cm::dev_first(done))                                                                                                \
             CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_w_kernel<LH, PR, FU, TP, CA>),                   \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                                \
-        hipLaunchKernelGGL((rollout_w_kernel<LH, PR, FU, TP, CA>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, a, ww, d, t, out, c); \
+        hipLaunchKernelGGL((rollout_w_kernel<LH, PR, FU, TP, CA>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, a, ww, d, t, out, c, tl); \
     } while (0)
 #define CM_RW2(LH) do { if (use_tape) CM_RW(LH, false, false, true, false);                                                     \
                         else if (carry) { if (full) CM_RW(LH, true, true, false, true); else CM_RW(LH, true, false, false, true); } \

@@ -913,20 +913,29 @@ class CommCategoricalMLPPolicy(CommBaseNet):
 
     @torch.no_grad()
     def chunk_fused(self, env_batch, n_steps, strides, obs, dist_adj, channels, step_out, greedy=False, out_actions=None,
-                    out_probs=None, out_attn=None, policy_step=0, step_base=None, env_id_offset=None):
+                    out_probs=None, out_attn=None, policy_step=0, step_base=None, env_id_offset=None, tail_next=None):
         """n_steps sampler iterations in ONE persistent launch (cm_rollout_chunk): pointers are those of the first
-        step, `strides` (_lib.ChunkStrides) the per-step element strides of the time-major buffers.  Returns False -
-        having done nothing - when the library has no fused kernel for this shape."""
+        step, `strides` (_lib.ChunkStrides) the per-step element strides of the time-major buffers.  tail_next = (obs,
+        dist_adj | None, channels | None) of the slot that receives the last step's outputs, with the advance of `step_base`
+        by n_steps (cm_rollout_chunk_tail: part of the same launch where the library can).  Returns False - having done
+        nothing - when the library has no fused kernel for this shape."""
         w = self._weights_struct()
+        eid = self.env_id_offset if env_id_offset is None else int(env_id_offset)
         with torch.cuda.device(obs.device):
-            rc = L.lib().cm_rollout_chunk(
-                env_batch._h, C.byref(w), int(n_steps), C.byref(strides), L.ptr(obs), L.ptr(dist_adj), L.ptr(channels),
-                self.seed, self.env_id_offset if env_id_offset is None else int(env_id_offset),
-                policy_step & 0xFFFFFFFF, L.ptr(step_base), int(greedy), L.ptr(out_actions), L.ptr(out_probs),
-                L.ptr(out_attn), C.byref(step_out), L.current_stream())
+            if tail_next is not None:
+                rc = L.lib().cm_rollout_chunk_tail(
+                    env_batch._h, C.byref(w), int(n_steps), C.byref(strides), L.ptr(obs), L.ptr(dist_adj), L.ptr(channels),
+                    self.seed, eid, policy_step & 0xFFFFFFFF, L.ptr(step_base), int(greedy), L.ptr(out_actions), L.ptr(out_probs),
+                    L.ptr(out_attn), C.byref(step_out), L.ptr(tail_next[0]), L.ptr(tail_next[1]), L.ptr(tail_next[2]),
+                    L.current_stream())
+            else:
+                rc = L.lib().cm_rollout_chunk(
+                    env_batch._h, C.byref(w), int(n_steps), C.byref(strides), L.ptr(obs), L.ptr(dist_adj), L.ptr(channels),
+                    self.seed, eid, policy_step & 0xFFFFFFFF, L.ptr(step_base), int(greedy), L.ptr(out_actions), L.ptr(out_probs),
+                    L.ptr(out_attn), C.byref(step_out), L.current_stream())
         if rc == 1:
             return False
-        L.check(rc, "cm_rollout_chunk")
+        L.check(rc, "cm_rollout_chunk_tail" if tail_next is not None else "cm_rollout_chunk")
         return True
 
     def get_actions(self, obs_n, avail_actions_n, dist_adj, channels, greedy=False):

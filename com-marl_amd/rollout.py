@@ -220,9 +220,10 @@ class RolloutEngine:
                               done=B, details=B * 6, dist_adj=B * N * N, channels=B * Lh * N * N, prey_alive=B * M,
                               success=B, path_len=B)
 
-    def steps_fused(self, t0, n, greedy=False):
-        """Slots t0 .. t0+n-1 in one persistent launch per shard (cm_rollout_chunk); False when the library has no
-        fused kernel for this shape (nothing was launched)."""
+    def steps_fused(self, t0, n, greedy=False, tail=False):
+        """Slots t0 .. t0+n-1 in one persistent launch per shard (cm_rollout_chunk); tail: followed by the chunk's tail - slot
+        t0+n into slot 0, Philox base += n (cm_rollout_chunk_tail: the same launch where the library can).  False when the
+        library has no fused kernel for this shape (nothing was launched)."""
         if self._fused is False or not hasattr(self.policy, "chunk_fused") or getattr(self.parts[0].cfg, "rng_mode", 0) != L.RNG_PHILOX:
             return False
         st = self._strides()
@@ -238,7 +239,9 @@ class RolloutEngine:
                     part._out(self._out(t0, lo, hi)), greedy=greedy, out_actions=self.actions[t0][lo:hi],
                     out_probs=None if self.probs is None else self.probs[t0][lo:hi],
                     out_attn=None if self.attn is None else self.attn[t0][lo:hi],
-                    policy_step=t0, step_base=self.step_bases[k], env_id_offset=self.id0 + lo)
+                    policy_step=t0, step_base=self.step_bases[k], env_id_offset=self.id0 + lo,
+                    tail_next=None if not tail else (self.obs[0][lo:hi], None if self.dist_adj is None else self.dist_adj[0][lo:hi],
+                                                     None if self.channels is None else self.channels[0][lo:hi]))
             if not ok:
                 assert k == 0, "fused chunk availability must not differ between shards"
                 self._fused = False
@@ -269,13 +272,7 @@ class RolloutEngine:
                         self._chunk_tail(k, t0 + n)
                 self.join()
             return
-        if self._persistent and self.steps_fused(t0, n):    # one launch per shard for the whole span
-            if tail:
-                self.fork()
-                for k, st in enumerate(self.streams):
-                    with torch.cuda.stream(st) if st is not None else _null():
-                        self._chunk_tail(k, t0 + n)
-                self.join()
+        if self._persistent and self.steps_fused(t0, n, tail=tail):    # one launch per shard for the whole span, its tail included
             return
         self.fork()
         for t in range(t0, t0 + n):

@@ -273,6 +273,18 @@ int cm_rollout_chunk(cm_env_t h, const cm_policy_weights *w, int32_t n_steps, co
                      int32_t env_id_offset, uint32_t policy_step, const uint32_t *policy_step_base, int32_t greedy,
                      int32_t *actions, float *probs, float *attn, const cm_step_out *out, void *stream);
 
+/* cm_rollout_chunk followed by cm_chunk_tail (below) for the same chunk: the observation (and masks, where the env produces
+ * them) the last step wrote - out->obs + (n_steps - 1) * strides->obs, ... - carried into obs_next / dist_adj_next /
+ * channels_next (slot 0 of the caller's ring; the mask pointers may be NULL) and *policy_step_base += n_steps.  Where the wave-owned
+ * kernel takes the chunk the tail is part of that launch (a wave writes its envs' next observation itself, the last wave to
+ * finish advances the counter): one launch per chunk; everywhere else the two launches of the separate calls.  Returns as
+ * cm_rollout_chunk (1: nothing was launched, tail included). */
+int cm_rollout_chunk_tail(cm_env_t h, const cm_policy_weights *w, int32_t n_steps, const cm_chunk_strides *strides,
+                          const float *obs, const float *dist_adj, const float *channels, uint64_t seed,
+                          int32_t env_id_offset, uint32_t policy_step, uint32_t *policy_step_base, int32_t greedy,
+                          int32_t *actions, float *probs, float *attn, const cm_step_out *out, float *obs_next,
+                          float *dist_adj_next, float *channels_next, void *stream);
+
 /* End of a chunk of rollout steps, in ONE launch: what the sampler loop does between two steps that a captured chunk
  * cannot leave to the host - `obses = next_obses` (centralized_ma_on_policy_vectorized_sampler.py:232): the slot the
  * last step wrote (src) becomes slot 0 (dst) for up to three buffers (observations, dist_adj, channels; bytes multiple
