@@ -37,6 +37,10 @@ template <int LHOPS, bool PRE, bool FULLWG, bool TAPE, bool CARRY = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rollout_w_kernel(mf::FwdArgs a, mw::WeightsW w, EnvDev p, cm_rng_tape tape_arg, cm_step_out out, StridesW c, TailW tl) {
     static_assert(!CARRY || (PRE && !TAPE), "the carried form is the prefetching, tape-less build");
     const cm_rng_tape tape = TAPE ? tape_arg : cm_rng_tape{};
+    // what the launcher has already established, as compile-time constants of the by-value config: the branches on them fold away
+    if constexpr (!TAPE) p.rng_mode = CM_RNG_PHILOX;                     // no tape pointers
+    p.scen = CM_PP; p.N = 4; p.lpe = 16; p.rcp_N = 0.25f; p.rcp_NN = 0.0625f;
+    if constexpr (CARRY) { p.adj_const = 1; p.ch_const = 1; p.channel = CM_CH_FC; }   // constant adjacency, no channel model
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_w[];
     constexpr int LPE = 16;
     constexpr int ACT_OFF = mw::pack_w(LHOPS).lds_u4 * 16, ENV_BASE = ACT_OFF + mw::WG_ROWS * 4;
