@@ -33,8 +33,16 @@ struct StridesW { int n_steps, obs, actions, probs, attn, reward, reward_f64, do
 // through LDS and registers (EnvCarry, env_pre_carry, the observation copy in the env area's unused claim table); no load of a
 // step depends on a store of the launch, so the fence between two steps goes and the trajectory stores of step t drain under
 // the policy forward of step t + 1.
-template <int LHOPS, bool PRE, bool FULLWG, bool TAPE, bool CARRY = false>
+// SHAPE 1 (carried builds): the grid of BASELINE config 2 - 10 x 10 cells, 4 preys, sensing range 1 (3 x 3 window, 21 observation
+// entries) - as compile-time constants: index divisions by constants, constant LDS offsets, unrolled element loops.
+template <int LHOPS, bool PRE, bool FULLWG, bool TAPE, bool CARRY = false, int SHAPE = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rollout_w_kernel(mf::FwdArgs a, mw::WeightsW w, EnvDev p, cm_rng_tape tape_arg, cm_step_out out, StridesW c, TailW tl) {
+    static_assert(SHAPE == 0 || CARRY, "shape constants are built into the carried form only");
+    if constexpr (SHAPE == 1) {
+        p.S = 10; p.M = 4; p.R = 1; p.W = 3; p.d = 21; p.rcp_d = 1.0f / 21.0f; p.rcp_W = 1.0f / 3.0f; p.rcp_WW = 1.0f / 9.0f;
+        p.lds_env = lds_env_bytes(10, 4, 4);
+        a.N = 4; a.d = 21; a.L = LHOPS;
+    }
     static_assert(!CARRY || (PRE && !TAPE), "the carried form is the prefetching, tape-less build");
     const cm_rng_tape tape = TAPE ? tape_arg : cm_rng_tape{};
     // what the launcher has already established, as compile-time constants of the by-value config: the branches on them fold away
@@ -177,14 +185,17 @@ int launch_rollout_w(mf::FwdArgs a, const cm_policy_weights *w, const void *w_pa
         tl = TailW{ chunk->tail_obs, chunk->tail_base, d.tail_ticket, 1 };
         *chunk->tail_folded = 1;
     }
-#define CM_RW(LH, PR, FU, TP, CA)                                                                                               \
+    static const int shape_flag = [] { const char *e = getenv("COMMARL_ROLLOUT_SHAPE"); return (e && e[0] == '0') ? 0 : 1; }();
+    const bool map10 = shape_flag && carry && d.S == 10 && d.M == 4 && d.R == 1 && d.W == 3 && d.d == 21 && d.lds_env == lds_env_bytes(10, 4, 4);
+#define CM_RW_(LH, PR, FU, TP, CA, SH)                                                                                          \
     do {                                                                                                                        \
         static unsigned long long done = 0;                                                                                     \
         if (cm::dev_first(done))                                                                                                \
-            CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_w_kernel<LH, PR, FU, TP, CA>),                   \
+            CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_w_kernel<LH, PR, FU, TP, CA, SH>),               \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                                \
-        hipLaunchKernelGGL((rollout_w_kernel<LH, PR, FU, TP, CA>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, a, ww, d, t, out, c, tl); \
+        hipLaunchKernelGGL((rollout_w_kernel<LH, PR, FU, TP, CA, SH>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, a, ww, d, t, out, c, tl); \
     } while (0)
+#define CM_RW(LH, PR, FU, TP, CA) do { if (CA && map10) CM_RW_(LH, PR, FU, TP, CA, (CA ? 1 : 0)); else CM_RW_(LH, PR, FU, TP, CA, 0); } while (0)
 #define CM_RW2(LH) do { if (use_tape) CM_RW(LH, false, false, true, false);                                                     \
                         else if (carry) { if (full) CM_RW(LH, true, true, false, true); else CM_RW(LH, true, false, false, true); } \
                         else if (pre) { if (full) CM_RW(LH, true, true, false, false); else CM_RW(LH, true, false, false, false); } \
@@ -192,6 +203,7 @@ int launch_rollout_w(mf::FwdArgs a, const cm_policy_weights *w, const void *w_pa
     if (d.L == 1) CM_RW2(1); else CM_RW2(2);
 #undef CM_RW2
 #undef CM_RW
+#undef CM_RW_
     CM_HIP(hipGetLastError());
     if (d.stop == -1) {                                                  // env phase clocks of workgroup 0 (ENV_PROBE, cm_env_dev.h)
         unsigned long long hp[16];

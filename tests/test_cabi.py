@@ -149,7 +149,9 @@ def test_fused_step_kernels_use_no_flat_or_scratch_addressing(tmp_path):
         assert re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1) == "0", name
         assert re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1) == "0", name
     assert seen >= 10, seen                                               # five shapes x two policy bodies (+ the full-workgroup builds)
-    for m in re.finditer(r"^(_ZN2cm19rollout_step_kernel\S+):\n(.*?)\n\.Lfunc_end", asm, re.M | re.S):
+    bodies = list(re.finditer(r"^(_ZN2cm19rollout_step_kernel\S+):[^\n]*\n(.*?)\n\.Lfunc_end", asm, re.M | re.S))
+    assert len(bodies) == seen                                            # (the label line carries a trailing "; @name" comment)
+    for m in bodies:
         assert not re.search(r"^\s+(flat_(load|store|atomic)|scratch_)", m.group(2), re.M), m.group(1)
 
 
@@ -177,7 +179,9 @@ def test_wave_owned_rollout_kernels_use_no_flat_or_scratch_addressing(tmp_path):
         seen += 1
         assert re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1) == "0", name
         assert re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1) == "0", name
-    assert seen == 14, seen     # 1 / 2 hops x (env prefetch on / off x full / ragged workgroups + the tape variant + carried full / ragged)
-    for m in re.finditer(r"^(_ZN2cm16rollout_w_kernel\S+):\n(.*?)\n\.Lfunc_end", asm, re.M | re.S):
+    assert seen == 18, seen     # 1 / 2 hops x (env prefetch on / off x full / ragged workgroups + the tape variant + carried full / ragged, generic and map10 shape)
+    bodies = list(re.finditer(r"^(_ZN2cm16rollout_w_kernel\S+):[^\n]*\n(.*?)\n\.Lfunc_end", asm, re.M | re.S))
+    assert len(bodies) == seen                                            # (the label line carries a trailing "; @name" comment)
+    for m in bodies:
         assert not re.search(r"^\s+(flat_(load|store|atomic)|scratch_)", m.group(2), re.M), m.group(1)
         assert len(re.findall(r"^\s+s_barrier", m.group(2), re.M)) == 1, "one workgroup barrier per launch (behind the weight staging)"
