@@ -237,7 +237,56 @@ __device__ __forceinline__ void emit(const EnvDev &p, const Lds l, const Rng rng
     const int S = p.S, N = p.N, M = p.M, R = p.R, W = p.W, d = p.d, WW = W * W, sl = g.sl;
     const float rcp_d = p.rcp_d, rcp_W = p.rcp_W, rcp_N = p.rcp_N, rcp_WW = p.rcp_WW, rcp_NN = p.rcp_NN;
     // ---- observations [N*d], lanes stride the flattened row -> coalesced stores ----
-    if (out.obs && tabs.held) {
+    if (out.obs && tabs.held && LPE == 16) {
+        // 16 lanes per env (small teams; the carried rollout): 6 elements per lane and pass, in stages - every position read of the pass
+        // is requested before the first tile probe, every probe before the first store (the LDS copy's stores would otherwise order every
+        // later LDS read behind them).  +1.5 % on the headline step; with 64 lanes per env (large teams) the plain loop below is as fast.
+        float *o = out.obs + (size_t)b * N * d;
+        const int total = N * d;
+        constexpr int U = 6;
+        for (int k0 = 0; k0 < total; k0 += U * LPE) {                   // uniform trip count: every lane takes part in the shuffles
+            int kk[U], ii[U], ff[U], r0[U], c0[U];
+            bool on[U];
+            float vv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = k0 + u * LPE + sl;
+                on[u] = k < total;
+                kk[u] = on[u] ? k : 0;
+                ii[u] = fdiv(kk[u], d, rcp_d); ff[u] = kk[u] - ii[u] * d;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) { r0[u] = AR(l, ii[u]); c0[u] = AC(l, ii[u]); }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int f = ff[u];
+                const float vrow = __shfl(tabs.row, r0[u], LPE), vcol = __shfl(tabs.col, c0[u], LPE);
+                float v;
+                if (SCEN == CM_PP) {
+                    if (f < 2 * WW) {                                   // get_neighbors (predator_prey.py:173-181)
+                        const int chn = f >= WW, w = f - chn * WW, wr = fdiv(w, W, rcp_W), wc = w - wr * W;
+                        v = (cell(l, r0[u] - R + wr, c0[u] - R + wc, S) == (chn ? C_PREY : C_AGENT)) ? 1.0f : 0.0f;
+                    } else v = f == 2 * WW ? vrow : (f == 2 * WW + 1 ? vcol : tabs.step);      // (:195-196)
+                } else {
+                    if (f < 3 * WW) {                                   // get_local_view (coverage.py:448-480)
+                        const int chn = fdiv(f, WW, rcp_WW), w = f - chn * WW, wr = fdiv(w, W, rcp_W), wc = w - wr * W;
+                        const int rr = r0[u] - R + wr, cc = c0[u] - R + wc;
+                        const bool in = in_grid(rr, cc, S);
+                        if (chn == 0) v = (!in || Gc(l, rr * S + cc) == C_WALL) ? 1.0f : 0.0f;
+                        else if (chn == 1) v = (in && Gc(l, rr * S + cc) == C_AGENT) ? 1.0f : 0.0f;
+                        else v = (in && ((VISW(l, rr, cc) >> (cc & 31)) & 1u)) ? 1.0f : 0.0f;
+                    } else v = f == 3 * WW ? vrow : (f == 3 * WW + 1 ? vcol : tabs.step);      // (:206)
+                }
+                vv[u] = v;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (on[u]) o[kk[u]] = vv[u];
+                // the persistent rollout keeps a copy for its next policy forward (rows of OBS_COPY_STRIDE floats in the env's LDS area)
+                if (on[u] && obs_copy >= 0) reinterpret_cast<float *>(smem + obs_copy)[ii[u] * OBS_COPY_STRIDE + ff[u]] = vv[u];
+            }
+        }
+    } else if (out.obs && tabs.held) {
         float *o = out.obs + (size_t)b * N * d;
         const int total = N * d;
         for (int k0 = 0; k0 < total; k0 += LPE) {                       // uniform trip count: every lane takes part in the shuffles
@@ -264,7 +313,6 @@ __device__ __forceinline__ void emit(const EnvDev &p, const Lds l, const Rng rng
                 } else v = f == 3 * WW ? vrow : (f == 3 * WW + 1 ? vcol : tabs.step);      // (:206)
             }
             if (on) o[k] = v;
-            // the persistent rollout keeps a copy for its next policy forward (rows of OBS_COPY_STRIDE floats in the env's LDS area)
             if (on && obs_copy >= 0) reinterpret_cast<float *>(smem + obs_copy)[i * OBS_COPY_STRIDE + f] = v;
         }
     } else if (out.obs) {
