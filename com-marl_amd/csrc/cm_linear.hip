@@ -314,7 +314,9 @@ extern "C" int cm_linear_act_backward(int64_t R, int32_t K, int32_t O, const flo
     const int OT = (O + 15) / 16, KT = (K + 15) / 16, NT = OT * KT;
     const size_t lds = ((size_t)lin::ROWS * (OT * 16 + 16) + (size_t)lin::ROWS * (KT * 16 + 16)) * sizeof(float);
     const long chunks = (R + lin::ROWS - 1) / lin::ROWS;
-    const int blocks = (int)std::min<long>(chunks, 512);
+    int blocks = (int)std::min<long>(chunks, 512);
+    static const int force = [] { const char *e = getenv("COMMARL_LIN_BLOCKS"); return e ? atoi(e) : 0; }();
+    if (force > 0) blocks = (int)std::min<long>(chunks, force);
     const hipStream_t st = (hipStream_t)stream;
     const int per_wave = (NT + 3) / 4;
     static unsigned long long once = 0;

@@ -12,7 +12,7 @@ L = importlib.import_module("com_marl_amd._lib")
 R, K, O = (int(a) for a in sys.argv[1:4])
 dev = torch.device("cuda:0")
 x = torch.tanh(torch.randn(R, K, device=dev))
-y = torch.tanh(torch.randn(R, O, device=dev))
+y = torch.tanh(torch.randn(R, O, device=dev)) if os.environ.get("NO_ACT") is None else None
 dy = torch.randn(R, O, device=dev)
 w = torch.randn(O, K, device=dev) * 0.1
 dx = torch.empty_like(x)
@@ -34,4 +34,4 @@ for _ in range(50):
     run()
 e1.record()
 torch.cuda.synchronize()
-print(f"R={R} K={K} O={O} blocks={os.environ.get('COMMARL_LIN2_BLOCKS', 'default')}: {e0.elapsed_time(e1) / 50 * 1e3:.1f} us", flush=True)
+print(f"R={R} K={K} O={O} blocks={os.environ.get('COMMARL_LIN2_BLOCKS', os.environ.get('COMMARL_LIN_BLOCKS', 'default'))}: {e0.elapsed_time(e1) / 50 * 1e3:.1f} us", flush=True)
