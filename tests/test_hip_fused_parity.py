@@ -12,6 +12,8 @@ SHAPES = {
     # every workgroup full (a multiple of 8 envs): the constant-shape build with the env state prefetched in front of
     # the policy forward (rollout_step_kernel<..., FULL, PRE>, cm_fused.hip)
     "pp_map10_full": ("pp", 10, 1, 4, 4, 2, 0.0, 208, 40, 9),
+    # 6 preys on the same grid: the carried rollout kernel in its run-time-shape build (the two shapes above take the map10 shape build)
+    "pp_map10_m6": ("pp", 10, 1, 4, 6, 2, 0.0, 41, 30, 8),
     # one GCN hop, no skip connection, range adjacency + IID loss (masks read by the wave-owned kernel), 5 preys; ragged batch
     "pp_map10_hop1": ("pp", 10, 1, 4, 5, 2, 0.3, 77, 24, 7),
     "co_map20": ("co", 20, 2, 24, 0, 2, 0.0, 7, 14, 6),
