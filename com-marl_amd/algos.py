@@ -512,15 +512,21 @@ class CentralizedMAPPO:
             o, a, r, v, bl, da, ch, adv_mb, oll_mb, ret_mb = mb
             main = torch.cuda.current_stream(obs.device)
             side = self._side_stream if two_streams else main
-            # critic: Gaussian NLL, mean over padded steps (comm_base_critic.py:88-89)
             self._baseline_optimizer.zero_grad()
             self._optimizer.zero_grad()
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                bl_loss = self._baseline_loss(o, ret_mb, da, ch)
-                (bl_loss * n_crit if distributed else bl_loss).backward()
-                if not distributed:
-                    self._baseline_optimizer.step()
+            side.wait_stream(main)                                               # fork: both nets see the minibatch, nothing else
+
+            def critic():                                                        # Gaussian NLL, mean over padded steps (comm_base_critic.py:88-89)
+                with torch.cuda.stream(side):
+                    bl_loss = self._baseline_loss(o, ret_mb, da, ch)
+                    (bl_loss * n_crit if distributed else bl_loss).backward()
+                    if not distributed:
+                        self._baseline_optimizer.step()
+            # Issue order: the policy's chain is the longer one, and a captured graph submits its nodes in capture order - with the
+            # critic first the policy's first kernel of a replayed step started ~110 us late (kernel trace of the reference-batch
+            # step).  The distributed step keeps the critic first: its gradients must be there when the bucket is reduced.
+            if distributed:
+                critic()
             loss_sum, n_valid = self._compute_loss(itr, o, None, a, r, v, bl, da, ch, adv_mb, oll_mb, reduce=False)
             if distributed:
                 loss_sum.backward()
@@ -539,6 +545,8 @@ class CentralizedMAPPO:
                 self._optimizer.step()                                           # _optimize (:606-610)
             if distributed:
                 self._baseline_optimizer.step()
+            else:
+                critic()
             main.wait_stream(side)
             return gn
 
