@@ -83,8 +83,9 @@ class _UpdateGraphs:
         obs = minibatches[0][0]
         if (mode == "0" or distributed or not obs.is_cuda or E < 3
                 or not all(hasattr(o, "begin_device_steps") for o in (algo._optimizer, algo._baseline_optimizer))
-                or not _fused_loss_ok(algo.policy, obs, None, minibatches[0][1], minibatches[0][3])):   # (the framework's Categorical
-            return None                                                                                # validates on the host)
+                or not _fused_loss_ok(algo.policy, obs, None, minibatches[0][1], minibatches[0][3])    # (the framework's Categorical
+                or not all(getattr(n, "_graph_capturable_update", False) for n in (algo.policy, algo.baseline))):   # validates on the host)
+            return None                                      # only the nets whose whole step is this library's launches (CommBaseNet)
         rows = max(mb[0].shape[0] for mb in minibatches) * T * getattr(algo.policy, "_n_agents", 1)
         if mode != "1" and rows > cls.MAX_ROWS:
             return None

@@ -628,6 +628,7 @@ class _WeightPack:
 
 class CommBaseNet(_WeightPack, nn.Module):
     """comm_base_net.py:11-111."""
+    _graph_capturable_update = True      # algos._UpdateGraphs: forward, loss and backward of these nets wait for nothing on the host
 
     def __init__(self, env_spec, n_agents, encoder_hidden_sizes=(128,), embedding_dim=64, attention_type="general",
                  n_gcn_layers=2, gcn_bias=True, state_include_actions=False, name="comm_base", residual=True,
@@ -1012,6 +1013,8 @@ class CommBaseCritic(CommBaseNet):
         if aggregator_type not in ("sum", "direct"):
             raise ValueError("aggregator_type must be 'sum' or 'direct' (comm_base_critic.py:46-49)")
         self.aggregator_type = aggregator_type
+        if aggregator_type != "sum" or n_agents > MAX_FUSED_AGENTS:
+            self._graph_capturable_update = False        # framework GEMMs / per-layer fallbacks in the step: eager
         self._dec_hidden = tuple(decoder_hidden_sizes)
         # 'sum': one value per agent from its embedding, summed (:110-112).  'direct': ONE value from the concatenated
         # embeddings of the whole team (:113-116) - the head is then a plain [N * 64] -> 64 -> 1 MLP on the framework's GEMMs
