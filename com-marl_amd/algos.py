@@ -66,15 +66,18 @@ def _dist_ready():
 
 
 class _UpdateGraphs:
-    """hipGraphs of the optimiser steps of one train_once: the reference walks the SAME minibatches in each of its mini-epochs
-    (centralized_ma_ppo.py:209-268: one permutation per epoch), so a minibatch's step is the same ~130 launches on the same
+    """hipGraphs of the optimiser steps of train_once: the reference walks the SAME minibatches in each of its mini-epochs
+    (centralized_ma_ppo.py:209-268: one permutation per epoch), so a minibatch's step is the same ~70 launches on the same
     buffers every time - only the weights, the Adam moments and the step number differ, and those live in device memory
     (optim.Adam.begin_device_steps).  The first mini-epoch of a process goes eagerly (first-use set-up inside the library,
     Adam's moments); after that a minibatch's step is captured the first time it comes up and every later step is one graph
-    launch.  For small batches the step is launch-bound (~3 ms of host work per step at the reference's 30 000 agent-steps per
-    epoch); large batches keep the eager path (COMMARL_UPDATE_GRAPH=1 forces the graphs, =0 disables them; the default
-    threshold is in agent rows per minibatch)."""
+    launch.  The graphs outlive the epoch: a later epoch whose minibatch i has the same shapes (the usual case at a fixed
+    number of envs and path length) copies its tensors into the captured step's input buffers and replays - no capture at
+    all (a capture costs as much host time as ~5 replayed steps).  For small batches the step is launch-bound (~3 ms of
+    host work per eager step at the reference's 30 000 agent-steps per epoch); large batches keep the eager path
+    (COMMARL_UPDATE_GRAPH=1 forces the graphs, =0 disables them; the default threshold is in agent rows per minibatch)."""
     MAX_ROWS = 1 << 18
+    MAX_CACHED = 12
 
     @classmethod
     def maybe(cls, algo, minibatches, T, distributed):
@@ -83,42 +86,80 @@ class _UpdateGraphs:
         obs = minibatches[0][0]
         if (mode == "0" or distributed or not obs.is_cuda or E < 3
                 or not all(hasattr(o, "begin_device_steps") for o in (algo._optimizer, algo._baseline_optimizer))
+                or E * len(minibatches) > algo._optimizer.DEV_STEP_CAPACITY
                 or not _fused_loss_ok(algo.policy, obs, None, minibatches[0][1], minibatches[0][3])    # (the framework's Categorical
                 or not all(getattr(n, "_graph_capturable_update", False) for n in (algo.policy, algo.baseline))):   # validates on the host)
             return None                                      # only the nets whose whole step is this library's launches (CommBaseNet)
         rows = max(mb[0].shape[0] for mb in minibatches) * T * getattr(algo.policy, "_n_agents", 1)
         if mode != "1" and rows > cls.MAX_ROWS:
             return None
+        self = getattr(algo, "_update_graphs", None)
+        owner = (id(algo.policy), id(algo.baseline), id(algo._optimizer), id(algo._baseline_optimizer),
+                 next(algo.policy.parameters()).data_ptr(), next(algo.baseline.parameters()).data_ptr(), obs.device)
+        if self is None or self.owner != owner:
+            self = algo._update_graphs = cls(algo, owner)
         # the first optimiser steps of a process go eagerly (first-use set-up inside the library, Adam's moment buffers and norm
-        # workspace); from then on the captures open in mini-epoch 0
+        # workspace); from then on a step is replayed (or captured) from mini-epoch 0
         first = 0 if getattr(algo, "_eager_stepped", False) else 1
-        return cls(algo, len(minibatches), (E - first) * len(minibatches), first)
+        self._begin(len(minibatches), (E - first) * len(minibatches), first)
+        # what a captured step has baked in besides its tensors: part of the cache key
+        grp = lambda o: tuple((g["lr"], tuple(g["betas"]), g["eps"]) for g in o.param_groups)   # noqa: E731
+        self.hyper = (T, grp(algo._optimizer), grp(algo._baseline_optimizer), algo._lr_clip_range, algo._policy_ent_coeff,
+                      algo._entropy_regularzied, algo._clip_grad_norm, os.environ.get("COMMARL_CRITIC_STREAM", "1"))
+        return self
 
-    def __init__(self, algo, n_mb, n_steps, first_epoch):
-        self.algo, self.graphs, self.done, self.n_steps, self.first_epoch = algo, [None] * n_mb, 0, n_steps, first_epoch
+    def __init__(self, algo, owner):
+        self.algo, self.owner = algo, owner
+        self.cache = collections.OrderedDict()               # (minibatch index, shapes) -> [graph, output, input tensors]
         self.pool, self.stream = None, None
+        self.cur, self.done, self.n_steps, self.first_epoch = [], 0, 0, 1
+        self.armed, self.broken, self.hyper = False, False, None
+        self.captured = self.reused = 0                       # (counters: captures taken / earlier epochs' graphs taken over)
+
+    def _begin(self, n_mb, n_steps, first_epoch):
+        self.cur, self.done, self.n_steps, self.first_epoch = [None] * n_mb, 0, n_steps, first_epoch
         self.armed, self.broken = False, False
 
-    def step(self, i, fn):
-        """Step of minibatch i: replayed from its graph (captured on first use) -> the step's gradient-norm output.  A capture that
-        fails (an op of a custom net that waits for the host, ...) switches the rest of the epoch back to eager steps."""
+    def _key(self, i, inputs):
+        return (i, self.hyper) + tuple(None if t is None else (tuple(t.shape), t.dtype) for t in inputs)
+
+    def step(self, i, inputs, fn):
+        """Step of minibatch i on `inputs` (its tensors: fn(*inputs) issues the step): replayed from its graph -> the step's
+        gradient-norm output.  First time this epoch: the graph of an earlier epoch with the same shapes gets the tensors copied
+        into its input buffers, else the step is captured with these tensors as its input buffers.  A capture that fails
+        switches the rest of the epoch back to eager steps."""
         if self.broken:
-            return fn()
+            return fn(*inputs)
         if not self.armed:                                   # the moments exist, the step counts are known
             self.algo._optimizer.begin_device_steps(self.n_steps)
             self.algo._baseline_optimizer.begin_device_steps(self.n_steps)
             self.armed = True
-        if self.graphs[i] is None:
-            try:
-                self.graphs[i] = self._capture(fn)
-            except Exception as e:                           # noqa: BLE001 - whatever the capture tripped over, the step itself is fine
-                import warnings
-                warnings.warn(f"PPO update: hipGraph capture of the optimiser step failed ({type(e).__name__}: {e}); eager steps from here")
-                torch.cuda.synchronize()
-                self.close()
-                self.broken = True
-                return fn()
-        g, out = self.graphs[i]
+        if self.cur[i] is None:
+            key = self._key(i, inputs)
+            ent = self.cache.get(key)
+            if ent is not None and os.environ.get("COMMARL_UPDATE_GRAPH_REUSE", "1") != "0":
+                with torch.no_grad():
+                    for dst, src in zip(ent[2], inputs):
+                        if dst is not None and dst.data_ptr() != src.data_ptr():
+                            dst.copy_(src)
+                self.cache.move_to_end(key)
+                self.reused += 1
+            else:
+                try:
+                    g, out = self._capture(lambda: fn(*inputs))
+                except Exception as e:                       # noqa: BLE001 - whatever the capture tripped over, the step itself is fine
+                    import warnings
+                    warnings.warn(f"PPO update: hipGraph capture of the optimiser step failed ({type(e).__name__}: {e}); eager steps from here")
+                    torch.cuda.synchronize()
+                    self.close()
+                    self.broken = True
+                    return fn(*inputs)
+                ent = self.cache[key] = [g, out, list(inputs)]
+                self.captured += 1
+                while len(self.cache) > self.MAX_CACHED:
+                    self.cache.popitem(last=False)
+            self.cur[i] = ent
+        g, out = self.cur[i][0], self.cur[i][1]
         g.replay()
         self.done += 1
         return out
@@ -149,12 +190,12 @@ class _UpdateGraphs:
         return g, out
 
     def close(self):
-        """Book the replayed steps into the optimisers' host state and drop the graphs (idempotent)."""
+        """Book the epoch's replayed steps into the optimisers' host state (idempotent); the graphs stay for later epochs."""
         if self.armed:
             self.algo._optimizer.end_device_steps(self.done)
             self.algo._baseline_optimizer.end_device_steps(self.done)
             self.armed, self.done = False, 0
-        self.graphs = [None] * len(self.graphs) if self.graphs is not None else None
+        self.cur = [None] * len(self.cur)
 
 
 class CentralizedMAPPO:
@@ -201,6 +242,7 @@ class CentralizedMAPPO:
         st.pop("_side_stream", None)
         st.pop("_bucket", None)
         st.pop("_eager_stepped", None)                   # per process: the first optimiser steps of a process run eagerly
+        st.pop("_update_graphs", None)                   # hipGraphs of optimiser steps (rebuilt on demand)
         return st
 
     @staticmethod
@@ -507,10 +549,9 @@ class CentralizedMAPPO:
             self._side_stream = torch.cuda.Stream(device=obs.device)
         n_crits = [torch.tensor(float(mb[0].shape[0] * T), device=obs.device) for mb in minibatches]
 
-        def one_step(mb, n_crit):
+        def one_step(o, a, r, v, bl, da, ch, adv_mb, oll_mb, ret_mb, n_crit):
             """One optimiser step of both nets on one minibatch (:211-268) -> the squared pre-clip gradient norm (device scalar,
             optim.Adam) or the post-clip norm (host float, any other optimiser)."""
-            o, a, r, v, bl, da, ch, adv_mb, oll_mb, ret_mb = mb
             main = torch.cuda.current_stream(obs.device)
             side = self._side_stream if two_streams else main
             self._baseline_optimizer.zero_grad()
@@ -559,9 +600,9 @@ class CentralizedMAPPO:
             for mini_epoch in range(self._optimization_mini_epochs):
                 for i, mb in enumerate(minibatches):
                     if graphs is not None and mini_epoch >= graphs.first_epoch:
-                        gn = graphs.step(i, lambda mb=mb, i=i: one_step(mb, n_crits[i]))
+                        gn = graphs.step(i, tuple(mb) + (n_crits[i],), one_step)
                     else:
-                        gn = one_step(mb, n_crits[i])
+                        gn = one_step(*mb, n_crits[i])
                         self._eager_stepped = True
                     grad_norm.append(gn.clone() if torch.is_tensor(gn) else gn)
         finally:

@@ -25,18 +25,29 @@ class Adam(torch.optim.Optimizer):
     # ------------------------------------------------------------------------------------------
     # device-side step counter: lets ONE captured hipGraph of an optimiser step be replayed for successive steps
     # ------------------------------------------------------------------------------------------
+    DEV_STEP_CAPACITY = 256      # optimiser steps one begin_device_steps() can cover (the reference schedule takes 30 per epoch)
+
     def begin_device_steps(self, n_steps):
         """From now until end_device_steps(), step() reads the bias corrections of step `step + 1 + cursor` from a device table
-        and advances the device cursor itself (both captured with the step); the host-side ``state[p]['step']`` stands still."""
+        and advances the device cursor itself (both captured with the step); the host-side ``state[p]['step']`` stands still.
+        Table and cursor are allocated once per optimiser and refilled in place: a hipGraph captured in one epoch can be
+        replayed in a later one."""
         ps = [p for g in self.param_groups for p in g["params"] if p.grad is not None or self.state[p]]
         steps = {int(self.state[p]["step"]) for p in ps if self.state[p]}
         assert len(steps) == 1 and len(self.param_groups) == 1, "device steps: one parameter group that has stepped together"
+        assert 1 <= n_steps <= self.DEV_STEP_CAPACITY, "device steps: at most DEV_STEP_CAPACITY steps per begin_device_steps()"
         first = steps.pop() + 1
         b1, b2 = self.param_groups[0]["betas"]
-        host = torch.empty(n_steps, 2, dtype=torch.float32)
+        host = torch.zeros(self.DEV_STEP_CAPACITY, 2, dtype=torch.float32)
         L.lib().cm_adam_bias_corrections(float(b1), float(b2), first, n_steps, host.data_ptr())
         dev = ps[0].device
-        self._dev_steps = dict(table=host.to(dev), cursor=torch.zeros(1, dtype=torch.int32, device=dev), n=n_steps, params=ps)
+        buf = getattr(self, "_dev_step_buf", None)
+        if buf is None or buf[0].device != dev:
+            buf = self._dev_step_buf = (torch.zeros(self.DEV_STEP_CAPACITY, 2, dtype=torch.float32, device=dev),
+                                        torch.zeros(1, dtype=torch.int32, device=dev))
+        buf[0].copy_(host)
+        buf[1].zero_()
+        self._dev_steps = dict(table=buf[0], cursor=buf[1], n=n_steps, params=ps)
 
     def end_device_steps(self, n_done):
         """Book the `n_done` replayed steps into the host-side state (and the parameters' version counters)."""
@@ -97,7 +108,7 @@ class Adam(torch.optim.Optimizer):
                         n, arr(ps), arr(grads), arr([self.state[p]["exp_avg"] for p in ps]),
                         arr([self.state[p]["exp_avg_sq"] for p in ps]), sizes, norm_ptr,
                         float(max_norm if max_norm is not None else 0.0), float(group["lr"]), float(b1), float(b2),
-                        float(group["eps"]), ds["table"].data_ptr(), ds["cursor"].data_ptr(), ds["n"], L.current_stream()),
+                        float(group["eps"]), ds["table"].data_ptr(), ds["cursor"].data_ptr(), self.DEV_STEP_CAPACITY, L.current_stream()),
                         "cm_multi_adam_step_dev")
                     ds["cursor"].add_(1)
                 else:
