@@ -234,6 +234,23 @@ extern "C" int cm_policy_forward_saved(const cm_policy_weights *w, int32_t S, co
     return policy_forward_h(w, w->mfma_pack + lo.total, a, stream);
 }
 
+namespace cm { int policy_forward_w_train(const cm_policy_weights *w, const void *w_pack, mf::FwdArgs a, void *stream); }   // cm_policy_w.hip
+
+extern "C" int cm_policy_forward_saved_wave(const cm_policy_weights *w, int32_t S, const float *obs, const float *adj, const float *chan,
+                                            float *attn, const cm_fwd_saves *sv, void *stream) {
+    using namespace cm;
+    if (!w || !obs || !sv) return set_error(CM_ERR_ARG, "cm_policy_forward_saved_wave: null argument");
+    if (S <= 0) return CM_OK;
+    if (!w->mfma_pack || !policy_shape_ok(w) || policy_pack_w_bytes(w) == 0) return 1;
+    mf::FwdArgs a{};
+    a.S = S; a.N = w->n_agents; a.d = w->d; a.L = w->n_hops;
+    a.obs = obs; a.adj = adj; a.chan = chan; a.attn = attn; a.no_residual = w->no_residual;
+    set_saves(a, sv);
+    a.probs = sv->probs;
+    const mf::PackLayout lo = mf::pack_layout(mf::kpad_of(w->d), w->n_hops, true);
+    return policy_forward_w_train(w, reinterpret_cast<const char *>(w->mfma_pack + lo.total) + policy_pack_h_bytes(w->d, w->n_hops, true), a, stream);
+}
+
 extern "C" int cm_critic_forward_saved(const cm_critic_weights *w, int32_t S, const float *obs, const float *adj, const float *chan,
                                        float *attn, float *values, const cm_fwd_saves *sv, void *stream) {
     using namespace cm;

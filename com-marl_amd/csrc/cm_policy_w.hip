@@ -20,6 +20,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     fwd_body_w<LHOPS>(a, w, lds_w, blockIdx.x, nullptr);
 }
 
+// Training forward: a persistent workgroup per CU stages the weights ONCE and walks its share of the 64-row blocks (a wave owns a
+// 16-row tile at a time, one wave per SIMD, nothing but registers between two layers); every activation the backward needs is
+// stored from the epilogue registers (policy_tile_w<.., TRAIN>).
+template <int LHOPS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void train_fwd_w_kernel(FwdArgs a, WeightsW w, int n_blk) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_w[];
+    stage_w<LHOPS>(w, lds_w, thread_x());
+    ResidentW res;
+    res.fetch<LHOPS>(w, thread_x() & 63);
+    __syncthreads();
+    for (int blk = blockIdx.x; blk < n_blk; blk += gridDim.x) {
+        asm volatile("" ::: "memory");                       // keep each block's loads inside its iteration
+        policy_tile_w<LHOPS, false, true>(a, w.n_act, res, lds_w, blk, nullptr);
+    }
+}
+
 // Wt [K][OUT] f32 (the ABI's transposed weights) -> A fragments with the wave-owned k order.
 // dst uint4 index ((ct * KB + q) * 2 + plane) * 64 + lane = halves e = 0..7 of W[o(ct, lane & 15)][k(q, lane >> 4, e)];
 //   natural = 1 (first layer: the observation arrives in memory order): k = 32 q + 8 g + e;  else k = kmap(q, g, e)
@@ -105,6 +121,26 @@ int policy_pack_w(const cm_policy_weights *w, void *dst, void *stream, int *bad)
     if (!w->enc_b1 || !w->enc_b2 || !w->hd_b1 || !w->hd_b2 || !w->hd_b3 || !w->hd_b4) return set_error(CM_ERR_ARG, "weight pack: null bias");
     hipLaunchKernelGGL(mw::pack_bias_w_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, w->enc_b1, w->enc_b2, w->gcn_b, w->hd_b1, w->hd_b2,
                        w->hd_b3, w->hd_b4, w->n_hops, w->n_act, reinterpret_cast<float *>(P + pk.bias));
+    CM_HIP(hipGetLastError());
+    return CM_OK;
+}
+
+// cm_policy_forward_saved_wave: 1 = no wave-owned instantiation for the shape (nothing launched)
+int policy_forward_w_train(const cm_policy_weights *w, const void *w_pack, mf::FwdArgs a, void *stream) {
+    if (!policy_w_enabled() || !mw::shape_ok_w(w->n_agents, w->d, w->n_hops, w->n_act) || a.avail) return 1;
+    const mw::WeightsW ww{ reinterpret_cast<const uint4 *>(w_pack), w->n_act };
+    const size_t lds = mw::lds_policy_bytes(w->n_hops);
+    const int n_blk = (a.S + mw::WG_ENVS - 1) / mw::WG_ENVS, blocks = std::min(n_blk, cm::cu_count());
+#define CM_TW(LH)                                                                                                              \
+    do {                                                                                                                       \
+        static unsigned long long done = 0;                                                                                    \
+        if (cm::dev_first(done))                                                                                               \
+            CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mw::train_fwd_w_kernel<LH>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                       160 * 1024));                                                                           \
+        hipLaunchKernelGGL((mw::train_fwd_w_kernel<LH>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, a, ww, n_blk);     \
+    } while (0)
+    if (w->n_hops == 1) CM_TW(1); else CM_TW(2);
+#undef CM_TW
     CM_HIP(hipGetLastError());
     return CM_OK;
 }

@@ -148,8 +148,11 @@ __device__ __forceinline__ void split_stage(const float (&y)[N], h16 (&h)[N], h1
 // taken in PAIRS (2p, 2p + 1) = k block p of the next layer's operand; the epilogue of pair p - 1 (join, tanh, split) is written
 // behind the MFMAs of pair p, so the vector ALU works in the matrix pipe's shadow.  keep (may be null): the f32 results
 // [CT] (the embedding E, which the residual needs again).
+// sv (may be null): this lane's row of a [rows][16 CT] f32 matrix that receives the layer's output (training forward: what the
+// backward pass reads back) - features 16 ct + 4 g .. + 3 of row c are one 16-byte store.
 template <int KB, int CT, bool TANH, bool BIAS>
-__device__ __forceinline__ void dense_act(const Frags<KB, CT> &f, const float *bias, const Act<KB> &x, Act<CT / 2> &y, v4f *keep, int lane) {
+__device__ __forceinline__ void dense_act(const Frags<KB, CT> &f, const float *bias, const Act<KB> &x, Act<CT / 2> &y, v4f *keep, int lane,
+                                          float *sv = nullptr) {
     const int g = lane >> 4;
     const v4f zero = (v4f){ 0.f, 0.f, 0.f, 0.f };
     v4f acc[CT];
@@ -177,6 +180,10 @@ __device__ __forceinline__ void dense_act(const Frags<KB, CT> &f, const float *b
             if (keep) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) keep[2 * (p - 1) + (e >> 2)][e & 3] = v[e];
+            }
+            if (sv) {
+                *reinterpret_cast<float4 *>(sv + 16 * (2 * (p - 1)) + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4 *>(sv + 16 * (2 * (p - 1) + 1) + 4 * g) = make_float4(v[4], v[5], v[6], v[7]);
             }
             h16 h[8], l[8];
             split_stage<8>(v, h, l);
@@ -248,7 +255,9 @@ struct ResidentW {
 // A ragged last workgroup (S % 16 != 0) computes on zero rows and stores nothing for them.
 // OBS_LDS: the observation rows come from an LDS copy the caller keeps (byte offset `obs_row` of this lane's row c, rows of
 // at least 24 floats with zeros behind the d real entries) instead of from a.obs - the carried rollout (cm_rollout_w.hip).
-template <int LHOPS, bool OBS_LDS = false>
+// TRAIN: the training forward (cm_policy_forward_saved_wave) - every activation the backward pass needs goes to the a.sv_* matrices
+// (layouts of cm_fwd_saves, include/commarl.h) straight from the epilogue registers; nothing is sampled.
+template <int LHOPS, bool OBS_LDS = false, bool TRAIN = false>
 __device__ __forceinline__ void policy_tile_w(const FwdArgs &a, int n_act, const ResidentW &res, const unsigned char *lds, int blk,
                                               int32_t *act_lds, int obs_row = 0) {
     static_assert(LHOPS >= 1 && LHOPS <= 2, "wave-owned forward: one or two hops");
@@ -290,12 +299,13 @@ __device__ __forceinline__ void policy_tile_w(const FwdArgs &a, int n_act, const
     // ---- encoder (every layer's fragments are fetched while the layer before it runs) ----
     Frags<1, 8> f_e1; f_e1.fetch(WL + pk.enc1, lane);
     Frags<4, 4> f_e2; f_e2.fetch(WL + pk.enc2, lane);
+    auto sv_row = [&](float *base, int width) -> float * { return (TRAIN && base && rv) ? base + grow * (size_t)width : nullptr; };
     Act<4> a1;
-    dense_act<1, 8, true, true>(f_e1, BL + bm.e1, xo, a1, nullptr, lane);
+    dense_act<1, 8, true, true>(f_e1, BL + bm.e1, xo, a1, nullptr, lane, sv_row(a.sv_a1, EH));
     Frags<2, 4> f_at; f_at.fetch(WL + pk.attn, lane);
     v4f E[4];
     Act<2> xe;
-    dense_act<4, 4, true, true>(f_e2, BL + bm.e2, a1, xe, E, lane);
+    dense_act<4, 4, true, true>(f_e2, BL + bm.e2, a1, xe, E, lane, sv_row(a.sv_e, EMB));
     Frags<2, 4> f_g; f_g.fetch(WL + pk.gcn, lane);
     CM_WPROBE(3);
 
@@ -303,7 +313,7 @@ __device__ __forceinline__ void policy_tile_w(const FwdArgs &a, int n_act, const
     float m[4];
     {
         Act<2> xq;
-        dense_act<2, 4, false, false>(f_at, nullptr, xe, xq, nullptr, lane);
+        dense_act<2, 4, false, false>(f_at, nullptr, xe, xq, nullptr, lane, sv_row(a.sv_q, EMB));
         v4f hh = (v4f){ 0.f, 0.f, 0.f, 0.f };
 #pragma unroll
         for (int q = 0; q < 2; ++q) { CM_MFW(xe.hi[q], xq.lo[q], hh); CM_MFW(xe.lo[q], xq.hi[q], hh); CM_MFW(xe.hi[q], xq.hi[q], hh); }
@@ -331,6 +341,17 @@ __device__ __forceinline__ void policy_tile_w(const FwdArgs &a, int n_act, const
     for (int l = 0; l < LHOPS; ++l) {
         v4f hw[4];                                             // H.Wg_l: rows 4 g + r, feature 16 ct + c
         dense_f32<2, 4, true, false>(f_g, nullptr, xh, hw, lane);
+        if constexpr (TRAIN) {
+            // H.Wg_l in the non-transposed form: this lane holds rows 4 g + r of the tile (env g of the wave), feature 16 ct + c.
+            // The pack folded the tanh prescale into Wg_l (the aggregation's output goes through tanh): taken out again here.
+            if (a.sv_hw[l] && s0 + wave * 4 + g < a.S) {
+                float *dst = a.sv_hw[l] + ((size_t)s0 * 4 + wave * 16 + 4 * g) * EMB + c;
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dst[(size_t)r * EMB + 16 * ct] = hw[ct][r] * (1.0f / TANH_PRESCALE);
+            }
+        }
         if (l + 1 < LHOPS) f_g.fetch(WL + pk.gcn + (l + 1) * frag_u4(EMB, EMB), lane);
         else f_x1.fetch(WL + pk.x1, lane);
         float cf[4], den = 0.0f;
@@ -382,6 +403,12 @@ __device__ __forceinline__ void policy_tile_w(const FwdArgs &a, int n_act, const
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += E[2 * p + (e >> 2)][e & 3];   // policy :74-77
             }
+            if constexpr (TRAIN) {
+                if (float *sv = sv_row(a.sv_h[l], EMB)) {
+                    *reinterpret_cast<float4 *>(sv + 16 * (2 * p) + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4 *>(sv + 16 * (2 * p + 1) + 4 * g) = make_float4(v[4], v[5], v[6], v[7]);
+                }
+            }
             h16 h[8], lo_[8];
             split_stage<8>(v, h, lo_);
 #pragma unroll
@@ -392,17 +419,20 @@ __device__ __forceinline__ void policy_tile_w(const FwdArgs &a, int n_act, const
     CM_WPROBE(6);
     // ---- head: 64 -> 128 -> 64 (resident fragments) -> 32 -> logits ----
     Act<4> x1;
-    dense_act<2, 8, true, true>(f_x1, BL + bm.b1, xh, x1, nullptr, lane);
+    dense_act<2, 8, true, true>(f_x1, BL + bm.b1, xh, x1, nullptr, lane, sv_row(a.sv_x1, H1));
     Frags<2, 2> f_h3; f_h3.fetch(WL + pk.h3, lane);
     Frags<1, 2> f_h4; f_h4.fetch(WL + pk.h4, lane);
     // the sampler's uniforms do not depend on the logits
-    const u32x4 xr = philox4x32_10((uint32_t)(a.env_id_offset + (int)env_g), draw_step, SITE_ACTION, (uint32_t)agent, a.key0, a.key1);
-    const float u = unit_f32(xr.x);
+    float u = 0.0f;
+    if constexpr (!TRAIN) {
+        const u32x4 xr = philox4x32_10((uint32_t)(a.env_id_offset + (int)env_g), draw_step, SITE_ACTION, (uint32_t)agent, a.key0, a.key1);
+        u = unit_f32(xr.x);
+    }
     CM_WPROBE(7);
     Act<2> x2;
-    dense_act<4, 4, true, true>(res.h2, BL + bm.b2, x1, x2, nullptr, lane);
+    dense_act<4, 4, true, true>(res.h2, BL + bm.b2, x1, x2, nullptr, lane, sv_row(a.sv_x2, H2));
     Act<1> x3;
-    dense_act<2, 2, true, true>(f_h3, BL + bm.b3, x2, x3, nullptr, lane);
+    dense_act<2, 2, true, true>(f_h3, BL + bm.b3, x2, x3, nullptr, lane, sv_row(a.sv_x3, H3));
     v4f lg[2];
     dense_f32<1, 2, false, true>(f_h4, BL + bm.b4, x3, lg, lane);    // lanes g == 0: logits 0..3 in lg[0], logit 4 in lg[1][0]
 
@@ -412,6 +442,12 @@ __device__ __forceinline__ void policy_tile_w(const FwdArgs &a, int n_act, const
     float p[MAX_ACT];
 #pragma unroll
     for (int cc = 0; cc < MAX_ACT; ++cc) p[cc] = cc < 4 ? lg[0][cc] : (cc == 4 ? lg[1][0] : 0.0f);
+    if constexpr (TRAIN) {
+        if (a.sv_out && g == 0 && rv) {                          // the logits, before softmax / avail mask
+#pragma unroll
+            for (int cc = 0; cc < 5; ++cc) if (cc < A) a.sv_out[grow * A + cc] = p[cc];
+        }
+    }
     float mx = -INFINITY, sum = 0.0f, msum = 0.0f;
 #pragma unroll
     for (int cc = 0; cc < 5; ++cc) if (cc < A) mx = fmaxf(mx, p[cc]);

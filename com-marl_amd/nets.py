@@ -375,12 +375,23 @@ class _FusedNetFn(torch.autograd.Function):
         adj_c = None if adj is None else adj.contiguous()
         ch_c = None if ch is None else ch.contiguous()
         net._train_fwd = True                          # the weight pack refreshes the f16-split section only (_WeightPack._packed)
+        # teams of 4, large batches: the wave-owned kernel of the rollout as training forward (cm_policy_forward_saved_wave: a
+        # persistent workgroup per CU, activations in registers: 0.97 -> 0.5 ms at 1.1 M agent rows); its fragments are the
+        # CM_PACK_WAVE section, refreshed together with the f16-split one then.  Small (launch-bound) batches keep the one section.
+        wave = (policy and N == 4 and S >= int(os.environ.get("COMMARL_TRAIN_FWD_WAVE_MIN", "16384"))
+                and os.environ.get("COMMARL_POLICY_KERNEL", "w")[0] not in "hfv")
+        net._train_fwd_wave = wave
         try:
             with torch.cuda.device(dev):
                 if policy:
                     w = net._weights_struct()
-                    rc = L.lib().cm_policy_forward_saved(C.byref(w), S, L.ptr(obs2), L.ptr(adj_c), L.ptr(ch_c), L.ptr(attn),
-                                                         C.byref(sv), L.current_stream())
+                    rc = 1
+                    if wave:
+                        rc = L.lib().cm_policy_forward_saved_wave(C.byref(w), S, L.ptr(obs2), L.ptr(adj_c), L.ptr(ch_c), L.ptr(attn),
+                                                                  C.byref(sv), L.current_stream())
+                    if rc == 1:
+                        rc = L.lib().cm_policy_forward_saved(C.byref(w), S, L.ptr(obs2), L.ptr(adj_c), L.ptr(ch_c), L.ptr(attn),
+                                                             C.byref(sv), L.current_stream())
                 else:
                     w = net._struct_from(net._packed())
                     w.mfma_pack = None if net._mfma is None else net._mfma.data_ptr()
@@ -388,7 +399,7 @@ class _FusedNetFn(torch.autograd.Function):
                     rc = L.lib().cm_critic_forward_saved(C.byref(w), S, L.ptr(obs2), L.ptr(adj_c), L.ptr(ch_c), L.ptr(attn),
                                                          L.ptr(vals), C.byref(sv), L.current_stream())
         finally:
-            net._train_fwd = False
+            net._train_fwd = net._train_fwd_wave = False
         if rc == 1:
             raise L.CommarlError("no saved-forward instantiation for this shape (caller should have checked _fused_train_ok)")
         L.check(rc, "cm_*_forward_saved")
@@ -530,7 +541,7 @@ class _Stacked(list):
 class _WeightPack:
     """Flat device copy of a net's (transposed) weights for the fused C-ABI kernels; subclasses list the
     tensors in ``_pack_tensors()``."""
-    _pack_sig, _pack, _pack_stale, _train_fwd = None, None, False, False
+    _pack_sig, _pack, _pack_stale, _train_fwd, _train_fwd_wave, _pack_fresh = None, None, False, False, False, 0
 
     def _pack_tensors(self):
         raise NotImplementedError
@@ -544,7 +555,8 @@ class _WeightPack:
         # refreshed (cm_*_pack_sections); the rest goes stale and is packed - with the range check - by the next no-grad user
         # (sync_weights() before a rollout, evaluate_nograd, act_device)
         partial = self._train_fwd and os.environ.get("COMMARL_PACK_PARTIAL", "1") != "0"
-        if sig == self._pack_sig and (partial or not self._pack_stale):
+        need = (L.PACK_F16 | (L.PACK_WAVE if self._train_fwd_wave else 0)) if partial else L.PACK_ALL
+        if sig == self._pack_sig and not (need & 7 & ~self._pack_fresh):     # every section this user reads is current
             return self._pack[1]
         with torch.no_grad():
             ts = self._pack_tensors()
@@ -562,9 +574,11 @@ class _WeightPack:
                 self._pack = (buf, ptrs, offs)
             buf, ptrs, offs = self._pack
             self._flat_copy(ts, buf, offs)
+            same = sig == self._pack_sig
             self._pack_sig = None                               # a refused pack (cm_*_pack: weight outside the f16 range) is retried
-            self._after_pack(self._pack[1], L.PACK_F16 if partial else L.PACK_ALL)
-            self._pack_sig, self._pack_stale = sig, partial
+            self._after_pack(self._pack[1], need)
+            self._pack_fresh = (need & 7) | (self._pack_fresh if same else 0)
+            self._pack_sig, self._pack_stale = sig, self._pack_fresh != 7
         return self._pack[1]
 
     def _flat_copy(self, ts, buf, offs):

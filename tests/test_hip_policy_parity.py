@@ -406,6 +406,48 @@ def test_fused_training_path_vs_per_layer_autograd(d, hops, residual, masks, N, 
             np.testing.assert_allclose(a[key][n_], b[key][n_], rtol=1e-4, atol=1e-5 * scale, err_msg=f"{key} {n_}")
 
 
+@pytest.mark.parametrize("hops,residual,masks,P,T", [(2, True, False, 7, 13), (2, True, True, 5, 64), (1, False, True, 3, 11)])
+def test_wave_owned_training_forward_matches_the_workgroup_tiled_one(hops, residual, masks, P, T, torch_cuda, monkeypatch):
+    """Teams of 4, large batches: the training forward on the rollout's wave-owned kernel (cm_policy_forward_saved_wave: a
+    persistent workgroup per CU, saves written from the epilogue registers) against cm_policy_forward_saved - same logits and
+    attention to 1e-5, every parameter gradient of the same backward chain to 1e-4 relative + 1e-5 of the tensor's largest entry
+    (the two forwards sum in another order).  Env counts that leave the last workgroup ragged and that wrap the persistent loop."""
+    torch = torch_cuda
+    from com_marl_amd import nets
+    from com_marl_amd.envs import EnvSpec, _Box, _Discrete
+    N, d = 4, 21
+    spec = EnvSpec(_Box(np.zeros(N * d), np.ones(N * d)), _Discrete(5))
+    torch.manual_seed(hops)
+    pol = nets.CommCategoricalMLPPolicy(spec, n_agents=N, n_gcn_layers=hops, residual=residual, device="cuda:0")
+    for n_, p_ in pol.named_parameters():
+        if n_.endswith("bias"):
+            torch.nn.init.uniform_(p_, -0.2, 0.2)
+    g = torch.Generator().manual_seed(9)
+    obs = torch.rand(P, T, N * d, generator=g).cuda()
+    adj = ch = None
+    if masks:
+        adj = (torch.rand(P, T, N, N, generator=g) < 0.7).float().cuda()
+        adj[..., torch.arange(N), torch.arange(N)] = 1.0
+        ch = (torch.rand(P, T, hops, N, N, generator=g) < 0.8).float().cuda()
+    actions = torch.randint(0, 5, (P, T, N), generator=g).cuda()
+    wts = torch.randn(P, T, generator=g).cuda()
+    res = {}
+    for tag, min_envs in (("wave", "1"), ("tiled", "1000000000")):
+        monkeypatch.setenv("COMMARL_TRAIN_FWD_WAVE_MIN", min_envs)
+        pol.zero_grad()
+        logits = pol._logits(obs, adj, ch)
+        dist = torch.distributions.Categorical(logits=logits)
+        loss = ((dist.log_prob(actions).sum(-1) + 0.1 * dist.entropy().mean(-1)) * wts).sum()
+        loss.backward()
+        res[tag] = dict(logits=logits.detach().cpu().numpy(), gp={n_: p_.grad.cpu().numpy().copy() for n_, p_ in pol.named_parameters()})
+    a, b = res["wave"], res["tiled"]
+    np.testing.assert_allclose(a["logits"], b["logits"], rtol=1e-5, atol=1e-5)
+    assert np.abs(a["logits"] - b["logits"]).max() > 0, "both runs took the same kernel"
+    for n_ in b["gp"]:
+        scale = max(1e-6, float(np.abs(b["gp"][n_]).max()))
+        np.testing.assert_allclose(a["gp"][n_], b["gp"][n_], rtol=1e-4, atol=1e-5 * scale, err_msg=n_)
+
+
 def test_evaluate_nograd_shares_one_forward(torch_cuda):
     """policy.evaluate_nograd (ONE launch giving logits and action probabilities: what train_once shares between the
     loss, the old log-likelihood and the KL / entropy diagnostics) returns the probabilities of act_device and logits whose
