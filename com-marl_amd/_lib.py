@@ -132,6 +132,8 @@ _SIGNATURES = {
                                   C.c_void_p]),
     "cm_policy_forward_saved_wave": (C.c_int, [C.POINTER(PolicyWeights), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.POINTER(FwdSaves), C.c_void_p]),
+    "cm_critic_forward_saved_wave": (C.c_int, [C.POINTER(CriticWeights), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.POINTER(FwdSaves), C.c_void_p]),
     "cm_policy_forward_saved": (C.c_int, [C.POINTER(PolicyWeights), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.POINTER(FwdSaves), C.c_void_p]),
     "cm_critic_forward_saved": (C.c_int, [C.POINTER(CriticWeights), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

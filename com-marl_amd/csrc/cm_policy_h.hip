@@ -237,16 +237,23 @@ int policy_pack_h(const cm_policy_weights *w, void *dst, int sections, void *str
     return mh::range_check_end(bad, stream, "cm_policy_pack");
 }
 
+int critic_pack_w(const cm_critic_weights *w, void *dst, void *stream, int *bad);   // cm_policy_w.hip
+
 int critic_pack_h(const cm_critic_weights *w, void *dst, int sections, void *stream) {
     const int kh = mh::kh_of(w->d);
-    if (!kh || !(sections & CM_PACK_F16)) return CM_OK;
+    if (!kh || !(sections & (CM_PACK_F16 | CM_PACK_WAVE))) return CM_OK;
     const mh::PackLayoutH lo = mh::pack_layout_h(kh, w->n_hops, false);
     uint4 *pack = reinterpret_cast<uint4 *>(dst);
     int *bad = (sections & CM_PACK_CHECK) ? mh::range_check_begin(stream) : nullptr;
-    mh::PackJobsH t{};
-    if (int rc = mh::pack_trunk_h(t, w->d, w->n_hops, w->enc_w1t, w->enc_w2t, w->attn_wt, w->gcn_w, kh, lo, pack, stream, bad)) return rc;
-    if (int rc = mh::pack_one_h(t, w->dec_w1t, mf::EMB, mf::DH, mf::EMB, mf::DH, pack + lo.x1, stream, bad)) return rc;
-    if (int rc = mh::pack_flush_h(t, stream, bad)) return rc;
+    if (sections & CM_PACK_F16) {
+        mh::PackJobsH t{};
+        if (int rc = mh::pack_trunk_h(t, w->d, w->n_hops, w->enc_w1t, w->enc_w2t, w->attn_wt, w->gcn_w, kh, lo, pack, stream, bad)) return rc;
+        if (int rc = mh::pack_one_h(t, w->dec_w1t, mf::EMB, mf::DH, mf::EMB, mf::DH, pack + lo.x1, stream, bad)) return rc;
+        if (int rc = mh::pack_flush_h(t, stream, bad)) return rc;
+    }
+    // teams of 4: the wave-owned training forward's fragments (cm_critic_forward_saved_wave), behind this section
+    if (sections & CM_PACK_WAVE)
+        if (int rc = critic_pack_w(w, reinterpret_cast<char *>(dst) + lo.total * sizeof(uint4), stream, bad)) return rc;
     return mh::range_check_end(bad, stream, "cm_critic_pack");
 }
 

@@ -234,7 +234,11 @@ extern "C" int cm_policy_forward_saved(const cm_policy_weights *w, int32_t S, co
     return policy_forward_h(w, w->mfma_pack + lo.total, a, stream);
 }
 
-namespace cm { int policy_forward_w_train(const cm_policy_weights *w, const void *w_pack, mf::FwdArgs a, void *stream); }   // cm_policy_w.hip
+namespace cm {                                       // cm_policy_w.hip
+int policy_forward_w_train(const cm_policy_weights *w, const void *w_pack, mf::FwdArgs a, void *stream);
+int critic_forward_w_train(const cm_critic_weights *w, const void *w_pack, mf::FwdArgs a, void *stream);
+size_t critic_pack_w_bytes(const cm_critic_weights *w);
+}
 
 extern "C" int cm_policy_forward_saved_wave(const cm_policy_weights *w, int32_t S, const float *obs, const float *adj, const float *chan,
                                             float *attn, const cm_fwd_saves *sv, void *stream) {
@@ -293,7 +297,22 @@ extern "C" int cm_policy_pack(const cm_policy_weights *w, float *pack, void *str
 
 extern "C" size_t cm_critic_pack_bytes(const cm_critic_weights *w) {
     if (!cm::critic_shape_ok(w)) return 0;
-    return cm::mf::pack_layout(cm::mf::kpad_of(w->d), w->n_hops, false).total * sizeof(float) + cm::policy_pack_h_bytes(w->d, w->n_hops, false);
+    return cm::mf::pack_layout(cm::mf::kpad_of(w->d), w->n_hops, false).total * sizeof(float) + cm::policy_pack_h_bytes(w->d, w->n_hops, false) +
+           cm::critic_pack_w_bytes(w);
+}
+
+extern "C" int cm_critic_forward_saved_wave(const cm_critic_weights *w, int32_t S, const float *obs, const float *adj, const float *chan,
+                                            float *attn, float *values, const cm_fwd_saves *sv, void *stream) {
+    using namespace cm;
+    if (!w || !obs || !sv) return set_error(CM_ERR_ARG, "cm_critic_forward_saved_wave: null argument");
+    if (S <= 0) return CM_OK;
+    if (!w->mfma_pack || !critic_shape_ok(w) || critic_pack_w_bytes(w) == 0) return 1;
+    mf::FwdArgs a{};
+    a.S = S; a.N = w->n_agents; a.d = w->d; a.L = w->n_hops;
+    a.obs = obs; a.adj = adj; a.chan = chan; a.attn = attn; a.values = values; a.no_residual = w->no_residual;
+    set_saves(a, sv);
+    const mf::PackLayout lo = mf::pack_layout(mf::kpad_of(w->d), w->n_hops, false);
+    return critic_forward_w_train(w, reinterpret_cast<const char *>(w->mfma_pack + lo.total) + policy_pack_h_bytes(w->d, w->n_hops, false), a, stream);
 }
 
 extern "C" int cm_critic_pack_sections(const cm_critic_weights *w, float *pack, int32_t sections, void *stream) {

@@ -23,16 +23,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // Training forward: a persistent workgroup per CU stages the weights ONCE and walks its share of the 64-row blocks (a wave owns a
 // 16-row tile at a time, one wave per SIMD, nothing but registers between two layers); every activation the backward needs is
 // stored from the epilogue registers (policy_tile_w<.., TRAIN>).
-template <int LHOPS>
+template <int LHOPS, int HEADK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void train_fwd_w_kernel(FwdArgs a, WeightsW w, int n_blk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_w[];
     stage_w<LHOPS>(w, lds_w, thread_x());
-    ResidentW res;
-    res.fetch<LHOPS>(w, thread_x() & 63);
+    ResidentW res{};
+    if constexpr (HEADK == 0) res.fetch<LHOPS>(w, thread_x() & 63);      // (the critic's head has no register-resident layer)
     __syncthreads();
     for (int blk = blockIdx.x; blk < n_blk; blk += gridDim.x) {
         asm volatile("" ::: "memory");                       // keep each block's loads inside its iteration
-        policy_tile_w<LHOPS, false, true>(a, w.n_act, res, lds_w, blk, nullptr);
+        policy_tile_w<LHOPS, false, true, HEADK>(a, w.n_act, res, lds_w, blk, nullptr);
+    }
+}
+
+// the critic's bias block in the policy's BiasMap: trunk as there, dec_b1 in the b1 slot (prescaled: tanh), dec_b2[0] in the b2 slot
+__global__ void pack_bias_wc_kernel(const float *e1, const float *e2, const float *gb, const float *d1, const float *d2, int L, float *__restrict__ dst) {
+    const BiasMap bm = bias_map(L);
+    for (int i = threadIdx.x; i < BIAS_U4 * 4; i += blockDim.x) {
+        float v = 0.0f;
+        if (i < bm.e2) v = e1[i] * TANH_PRESCALE;
+        else if (i < bm.g) v = e2[i - bm.e2] * TANH_PRESCALE;
+        else if (i < bm.b1) v = ((gb && i - bm.g < L * EMB) ? gb[i - bm.g] : 0.0f) * TANH_PRESCALE;
+        else if (i < bm.b1 + EMB) v = d1[i - bm.b1] * TANH_PRESCALE;
+        else if (i == bm.b2) v = d2[0];
+        dst[i] = v;
     }
 }
 
@@ -131,15 +145,53 @@ int policy_forward_w_train(const cm_policy_weights *w, const void *w_pack, mf::F
     const mw::WeightsW ww{ reinterpret_cast<const uint4 *>(w_pack), w->n_act };
     const size_t lds = mw::lds_policy_bytes(w->n_hops);
     const int n_blk = (a.S + mw::WG_ENVS - 1) / mw::WG_ENVS, blocks = std::min(n_blk, cm::cu_count());
-#define CM_TW(LH)                                                                                                              \
+#define CM_TW(LH, HK)                                                                                                          \
     do {                                                                                                                       \
         static unsigned long long done = 0;                                                                                    \
         if (cm::dev_first(done))                                                                                               \
-            CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mw::train_fwd_w_kernel<LH>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+            CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mw::train_fwd_w_kernel<LH, HK>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                        160 * 1024));                                                                           \
-        hipLaunchKernelGGL((mw::train_fwd_w_kernel<LH>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, a, ww, n_blk);     \
+        hipLaunchKernelGGL((mw::train_fwd_w_kernel<LH, HK>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, a, ww, n_blk); \
     } while (0)
-    if (w->n_hops == 1) CM_TW(1); else CM_TW(2);
+    if (w->n_hops == 1) CM_TW(1, 0); else CM_TW(2, 0);
+    CM_HIP(hipGetLastError());
+    return CM_OK;
+}
+
+// ---- the critic on the same kernel (training forward only): its fragments in the policy's image layout ----
+static bool critic_w_ok(const cm_critic_weights *w) {
+    return policy_w_enabled() && w->n_agents == 4 && w->d <= mw::KH && (w->n_hops == 1 || w->n_hops == 2) && w->enc_hidden == mf::EH &&
+           w->emb == mf::EMB && w->dec_hidden == mf::DH && mf::DH == mf::EMB;
+}
+size_t critic_pack_w_bytes(const cm_critic_weights *w) { return critic_w_ok(w) ? (size_t)mw::pack_w(w->n_hops).lds_u4 * sizeof(uint4) : 0; }
+
+int critic_pack_w(const cm_critic_weights *w, void *dst, void *stream, int *bad) {
+    if (!critic_w_ok(w)) return CM_OK;
+    const mw::PackW pk = mw::pack_w(w->n_hops);
+    uint4 *P = reinterpret_cast<uint4 *>(dst);
+    using namespace mf;
+    if (int rc = mw::pack_one_w(w->enc_w1t, w->d, EH, mw::KH, EH, true, false, true, P + pk.enc1, stream, bad)) return rc;
+    if (int rc = mw::pack_one_w(w->enc_w2t, EH, EMB, EH, EMB, false, false, true, P + pk.enc2, stream, bad)) return rc;
+    if (int rc = mw::pack_one_w(w->attn_wt, EMB, EMB, EMB, EMB, false, false, false, P + pk.attn, stream, bad)) return rc;
+    for (int l = 0; l < w->n_hops; ++l)
+        if (int rc = mw::pack_one_w(w->gcn_w ? w->gcn_w + (size_t)l * EMB * EMB : nullptr, EMB, EMB, EMB, EMB, false, false, true,
+                                    P + pk.gcn + l * mw::frag_u4(EMB, EMB), stream, bad)) return rc;
+    if (int rc = mw::pack_one_w(w->dec_w1t, EMB, DH, EMB, DH, false, false, true, P + pk.x1, stream, bad)) return rc;      // x1 slot
+    if (int rc = mw::pack_one_w(w->dec_w2t, DH, 1, DH, 16, false, false, false, P + pk.h3, stream, bad)) return rc;       // h3 slot, 16-wide tile
+    if (!w->enc_b1 || !w->enc_b2 || !w->dec_b1 || !w->dec_b2) return set_error(CM_ERR_ARG, "weight pack: null bias");
+    hipLaunchKernelGGL(mw::pack_bias_wc_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, w->enc_b1, w->enc_b2, w->gcn_b, w->dec_b1, w->dec_b2,
+                       w->n_hops, reinterpret_cast<float *>(P + pk.bias));
+    CM_HIP(hipGetLastError());
+    return CM_OK;
+}
+
+// cm_critic_forward_saved_wave: 1 = no wave-owned instantiation for the shape (nothing launched)
+int critic_forward_w_train(const cm_critic_weights *w, const void *w_pack, mf::FwdArgs a, void *stream) {
+    if (!critic_w_ok(w)) return 1;
+    const mw::WeightsW ww{ reinterpret_cast<const uint4 *>(w_pack), 0 };
+    const size_t lds = mw::lds_policy_bytes(w->n_hops);
+    const int n_blk = (a.S + mw::WG_ENVS - 1) / mw::WG_ENVS, blocks = std::min(n_blk, cm::cu_count());
+    if (w->n_hops == 1) CM_TW(1, 1); else CM_TW(2, 1);
 #undef CM_TW
     CM_HIP(hipGetLastError());
     return CM_OK;

@@ -257,9 +257,13 @@ struct ResidentW {
 // at least 24 floats with zeros behind the d real entries) instead of from a.obs - the carried rollout (cm_rollout_w.hip).
 // TRAIN: the training forward (cm_policy_forward_saved_wave) - every activation the backward pass needs goes to the a.sv_* matrices
 // (layouts of cm_fwd_saves, include/commarl.h) straight from the epilogue registers; nothing is sampled.
-template <int LHOPS, bool OBS_LDS = false, bool TRAIN = false>
+// HEADK 1: the critic's head behind the same trunk (training forward only; cm_critic_forward_saved_wave) - decoder layer 64 -> 64
+// (fragments in the policy's x1 slot of the image), value layer 64 -> 1 as a 16-wide tile (h3 slot), per-agent values to a.sv_out,
+// their sum over the team to a.values.  `res` is not touched then.
+template <int LHOPS, bool OBS_LDS = false, bool TRAIN = false, int HEADK = 0>
 __device__ __forceinline__ void policy_tile_w(const FwdArgs &a, int n_act, const ResidentW &res, const unsigned char *lds, int blk,
                                               int32_t *act_lds, int obs_row = 0) {
+    static_assert(HEADK == 0 || TRAIN, "the critic head exists as training forward only");
     static_assert(LHOPS >= 1 && LHOPS <= 2, "wave-owned forward: one or two hops");
     const int tid = thread_x(), wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
     constexpr PackW pk = pack_w(LHOPS);
@@ -336,7 +340,7 @@ __device__ __forceinline__ void policy_tile_w(const FwdArgs &a, int n_act, const
     CM_WPROBE(5);
     // ---- hops: H_{l+1} = tanh(A_l.(H_l.Wg_l) + b_l), A_l = M * Range * Chan_l renormalised (comm_base_net.py:99-105) ----
     Act<2> xh = xe;
-    Frags<2, 8> f_x1;
+    Frags<2, HEADK == 0 ? 8 : 4> f_x1;                          // first head layer: policy 64 -> 128, critic 64 -> 64
 #pragma unroll
     for (int l = 0; l < LHOPS; ++l) {
         v4f hw[4];                                             // H.Wg_l: rows 4 g + r, feature 16 ct + c
@@ -417,6 +421,20 @@ __device__ __forceinline__ void policy_tile_w(const FwdArgs &a, int n_act, const
     }
 
     CM_WPROBE(6);
+    if constexpr (HEADK == 1) {
+        // ---- critic head: 64 -> 64 (tanh) -> 1 (comm_base_critic.py:110-112), value of row c in the lanes g == 0 ----
+        Frags<2, 1> f_d2; f_d2.fetch(WL + pk.h3, lane);
+        Act<2> xd;
+        dense_act<2, 4, true, true>(f_x1, BL + bm.b1, xh, xd, nullptr, lane, sv_row(a.sv_x1, EMB));
+        v4f val[1];
+        dense_f32<2, 1, false, true>(f_d2, BL + bm.b2, xd, val, lane);
+        float v = (g == 0 && rv) ? val[0][0] : 0.0f;
+        if (a.sv_out && g == 0 && rv) a.sv_out[grow] = v;
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);                                   // the env's four agents are four neighbouring lanes
+        if (a.values && g == 0 && rv && agent == 0) a.values[(size_t)s0 + env_l] = v;
+        return;
+    } else {
     // ---- head: 64 -> 128 -> 64 (resident fragments) -> 32 -> logits ----
     Act<4> x1;
     dense_act<2, 8, true, true>(f_x1, BL + bm.b1, xh, x1, nullptr, lane, sv_row(a.sv_x1, H1));
@@ -483,6 +501,7 @@ __device__ __forceinline__ void policy_tile_w(const FwdArgs &a, int n_act, const
             if (a.actions) a.actions[grow] = act;
             if (act_lds) act_lds[row] = act;
         }
+    }
     }
     CM_WPROBE(10);
 }

@@ -378,7 +378,7 @@ class _FusedNetFn(torch.autograd.Function):
         # teams of 4, large batches: the wave-owned kernel of the rollout as training forward (cm_policy_forward_saved_wave: a
         # persistent workgroup per CU, activations in registers: 0.97 -> 0.5 ms at 1.1 M agent rows); its fragments are the
         # CM_PACK_WAVE section, refreshed together with the f16-split one then.  Small (launch-bound) batches keep the one section.
-        wave = (policy and N == 4 and S >= int(os.environ.get("COMMARL_TRAIN_FWD_WAVE_MIN", "16384"))
+        wave = (N == 4 and S >= int(os.environ.get("COMMARL_TRAIN_FWD_WAVE_MIN", "16384"))
                 and os.environ.get("COMMARL_POLICY_KERNEL", "w")[0] not in "hfv")
         net._train_fwd_wave = wave
         try:
@@ -396,8 +396,13 @@ class _FusedNetFn(torch.autograd.Function):
                     w = net._struct_from(net._packed())
                     w.mfma_pack = None if net._mfma is None else net._mfma.data_ptr()
                     vals = z(S)
-                    rc = L.lib().cm_critic_forward_saved(C.byref(w), S, L.ptr(obs2), L.ptr(adj_c), L.ptr(ch_c), L.ptr(attn),
-                                                         L.ptr(vals), C.byref(sv), L.current_stream())
+                    rc = 1
+                    if wave:
+                        rc = L.lib().cm_critic_forward_saved_wave(C.byref(w), S, L.ptr(obs2), L.ptr(adj_c), L.ptr(ch_c), L.ptr(attn),
+                                                                  L.ptr(vals), C.byref(sv), L.current_stream())
+                    if rc == 1:
+                        rc = L.lib().cm_critic_forward_saved(C.byref(w), S, L.ptr(obs2), L.ptr(adj_c), L.ptr(ch_c), L.ptr(attn),
+                                                             L.ptr(vals), C.byref(sv), L.current_stream())
         finally:
             net._train_fwd = net._train_fwd_wave = False
         if rc == 1:

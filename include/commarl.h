@@ -246,13 +246,15 @@ int cm_policy_forward_saved(const cm_policy_weights *w, int32_t n_samples, const
                             const float *channels, float *attn, const cm_fwd_saves *sv, void *stream);
 int cm_critic_forward_saved(const cm_critic_weights *w, int32_t n_samples, const float *obs, const float *dist_adj,
                             const float *channels, float *attn, float *values, const cm_fwd_saves *sv, void *stream);
-/* cm_policy_forward_saved for teams of 4 on the wave-owned kernel of the rollout (csrc/cm_policy_w_dev.h): one persistent
+/* cm_policy_forward_saved / cm_critic_forward_saved for teams of 4 on the wave-owned kernel of the rollout (csrc/cm_policy_w_dev.h): one persistent
  * workgroup per CU stages the weights once and walks the batch, a wave carries 16 agent rows through the whole net in registers
  * and stores the saved activations from there.  Needs the CM_PACK_WAVE section of the operand pack to be current (between
  * optimiser steps: cm_policy_pack_sections(..., CM_PACK_F16 | CM_PACK_WAVE, ...)).  Same saves, same values to the f16-split
- * kernels' rounding (1e-6 relative).  Returns 1 - nothing done - for every other shape: call cm_policy_forward_saved. */
+ * kernels' rounding (1e-6 relative).  Returns 1 - nothing done - for every other shape: call cm_policy_forward_saved / cm_critic_forward_saved. */
 int cm_policy_forward_saved_wave(const cm_policy_weights *w, int32_t n_samples, const float *obs, const float *dist_adj,
                                  const float *channels, float *attn, const cm_fwd_saves *sv, void *stream);
+int cm_critic_forward_saved_wave(const cm_critic_weights *w, int32_t n_samples, const float *obs, const float *dist_adj,
+                                 const float *channels, float *attn, float *values, const cm_fwd_saves *sv, void *stream);
 
 /* One rollout step in ONE launch: cm_policy_forward over the B envs of `h` followed, inside the same workgroups, by
  * cm_env_step on the sampled actions (which travel through LDS and are also written to `actions`): what one iteration

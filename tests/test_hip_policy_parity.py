@@ -419,9 +419,11 @@ def test_wave_owned_training_forward_matches_the_workgroup_tiled_one(hops, resid
     spec = EnvSpec(_Box(np.zeros(N * d), np.ones(N * d)), _Discrete(5))
     torch.manual_seed(hops)
     pol = nets.CommCategoricalMLPPolicy(spec, n_agents=N, n_gcn_layers=hops, residual=residual, device="cuda:0")
-    for n_, p_ in pol.named_parameters():
-        if n_.endswith("bias"):
-            torch.nn.init.uniform_(p_, -0.2, 0.2)
+    crit = nets.CommBaseCritic(spec, n_agents=N, n_gcn_layers=hops, residual=residual, device="cuda:0")
+    for net in (pol, crit):
+        for n_, p_ in net.named_parameters():
+            if n_.endswith("bias"):
+                torch.nn.init.uniform_(p_, -0.2, 0.2)
     g = torch.Generator().manual_seed(9)
     obs = torch.rand(P, T, N * d, generator=g).cuda()
     adj = ch = None
@@ -431,21 +433,30 @@ def test_wave_owned_training_forward_matches_the_workgroup_tiled_one(hops, resid
         ch = (torch.rand(P, T, hops, N, N, generator=g) < 0.8).float().cuda()
     actions = torch.randint(0, 5, (P, T, N), generator=g).cuda()
     wts = torch.randn(P, T, generator=g).cuda()
+    returns = torch.randn(P, T, generator=g).cuda()
     res = {}
     for tag, min_envs in (("wave", "1"), ("tiled", "1000000000")):
         monkeypatch.setenv("COMMARL_TRAIN_FWD_WAVE_MIN", min_envs)
-        pol.zero_grad()
+        pol.zero_grad(); crit.zero_grad()
         logits = pol._logits(obs, adj, ch)
         dist = torch.distributions.Categorical(logits=logits)
         loss = ((dist.log_prob(actions).sum(-1) + 0.1 * dist.entropy().mean(-1)) * wts).sum()
         loss.backward()
-        res[tag] = dict(logits=logits.detach().cpu().numpy(), gp={n_: p_.grad.cpu().numpy().copy() for n_, p_ in pol.named_parameters()})
+        values, _ = crit._values_grad(obs, adj, ch)
+        closs = crit.compute_loss(obs, returns, adj, ch)
+        closs.backward()
+        res[tag] = dict(logits=logits.detach().cpu().numpy(), values=values.detach().cpu().numpy(), closs=float(closs.detach()),
+                        gp={n_: p_.grad.cpu().numpy().copy() for n_, p_ in pol.named_parameters()},
+                        gc={n_: p_.grad.cpu().numpy().copy() for n_, p_ in crit.named_parameters() if p_.grad is not None})
     a, b = res["wave"], res["tiled"]
     np.testing.assert_allclose(a["logits"], b["logits"], rtol=1e-5, atol=1e-5)
-    assert np.abs(a["logits"] - b["logits"]).max() > 0, "both runs took the same kernel"
-    for n_ in b["gp"]:
-        scale = max(1e-6, float(np.abs(b["gp"][n_]).max()))
-        np.testing.assert_allclose(a["gp"][n_], b["gp"][n_], rtol=1e-4, atol=1e-5 * scale, err_msg=n_)
+    np.testing.assert_allclose(a["values"], b["values"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(a["closs"], b["closs"], rtol=1e-5)
+    assert np.abs(a["logits"] - b["logits"]).max() > 0 and np.abs(a["values"] - b["values"]).max() > 0, "both runs took the same kernel"
+    for key in ("gp", "gc"):
+        for n_ in b[key]:
+            scale = max(1e-6, float(np.abs(b[key][n_]).max()))
+            np.testing.assert_allclose(a[key][n_], b[key][n_], rtol=1e-4, atol=1e-5 * scale, err_msg=f"{key} {n_}")
 
 
 def test_evaluate_nograd_shares_one_forward(torch_cuda):
