@@ -515,10 +515,18 @@ def _fused_logits_nograd(net, obs, adj, ch, want_probs=False):
         sv.probs = probs.data_ptr()
     adj_c = None if adj is None else adj.contiguous()
     ch_c = None if ch is None else ch.contiguous()
+    # large batches of teams of 4: the same kernel the training forward takes (both sides of the PPO ratio from one arithmetic)
+    wave = (N == 4 and S >= int(os.environ.get("COMMARL_TRAIN_FWD_WAVE_MIN", "16384"))
+            and os.environ.get("COMMARL_POLICY_KERNEL", "w")[0] not in "hfv")
     with torch.cuda.device(obs.device):
-        w = net._weights_struct()
-        rc = L.lib().cm_policy_forward_saved(C.byref(w), S, L.ptr(obs2), L.ptr(adj_c), L.ptr(ch_c), L.ptr(attn), C.byref(sv),
-                                             L.current_stream())
+        w = net._weights_struct()                            # (no-grad user: every section of the pack is current)
+        rc = 1
+        if wave:
+            rc = L.lib().cm_policy_forward_saved_wave(C.byref(w), S, L.ptr(obs2), L.ptr(adj_c), L.ptr(ch_c), L.ptr(attn), C.byref(sv),
+                                                      L.current_stream())
+        if rc == 1:
+            rc = L.lib().cm_policy_forward_saved(C.byref(w), S, L.ptr(obs2), L.ptr(adj_c), L.ptr(ch_c), L.ptr(attn), C.byref(sv),
+                                                 L.current_stream())
     if rc == 1:
         raise L.CommarlError("no saved-forward instantiation for this shape")
     L.check(rc, "cm_policy_forward_saved")
