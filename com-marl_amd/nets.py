@@ -379,7 +379,7 @@ class _FusedNetFn(torch.autograd.Function):
         # persistent workgroup per CU, activations in registers: 0.97 -> 0.5 ms at 1.1 M agent rows); its fragments are the
         # CM_PACK_WAVE section, refreshed together with the f16-split one then.  Small (launch-bound) batches keep the one section.
         wave = (N == 4 and S >= int(os.environ.get("COMMARL_TRAIN_FWD_WAVE_MIN", "16384"))
-                and os.environ.get("COMMARL_POLICY_KERNEL", "w")[0] not in "hfv")
+                and (os.environ.get("COMMARL_POLICY_KERNEL") or "w")[0] not in "hfv")
         net._train_fwd_wave = wave
         try:
             with torch.cuda.device(dev):
@@ -517,7 +517,7 @@ def _fused_logits_nograd(net, obs, adj, ch, want_probs=False):
     ch_c = None if ch is None else ch.contiguous()
     # large batches of teams of 4: the same kernel the training forward takes (both sides of the PPO ratio from one arithmetic)
     wave = (N == 4 and S >= int(os.environ.get("COMMARL_TRAIN_FWD_WAVE_MIN", "16384"))
-            and os.environ.get("COMMARL_POLICY_KERNEL", "w")[0] not in "hfv")
+            and (os.environ.get("COMMARL_POLICY_KERNEL") or "w")[0] not in "hfv")
     with torch.cuda.device(obs.device):
         w = net._weights_struct()                            # (no-grad user: every section of the pack is current)
         rc = 1
